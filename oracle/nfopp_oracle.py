@@ -1,0 +1,509 @@
+"""CPU oracle for the NFOPP inner loop -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A numpy/fp32 restatement, with closed-form gradients and a leading batch axis, of the reference's
+planner step (MisterMap/pytorch-motion-planner, PyTorch-CPU + autograd).  It is the checker the HIP path is
+compared against; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.
+The product package (`pytorch-motion-planner_amd/nfopp`) never does.
+
+Pinned: every function below is checked in `tests/test_oracle_golden.py` against golden vectors produced by
+running the reference itself in the build container (`tests/golden/make_golden.py`, fixtures committed).
+
+Reference citations are `file:line` under the reference repo root; `nfop/` abbreviates
+`neural_field_optimal_planner/`.
+
+A batch of B trajectories is exactly B independent reference problems sharing one ONF (every loss term of
+the reference is a `torch.sum` over the waypoints of its single trajectory).
+"""
+import numpy as np
+
+F32 = np.float32
+PI = F32(np.pi)
+TWO_PI = F32(2 * np.pi)
+HIDDEN = 100
+
+
+# ----------------------------------------------------------------------------------------------------------
+# small helpers
+def wrap_angle(a):
+    """nfop/torch_math.py:5-7 -- (a + pi) % (2 pi) - pi with fp32 constants, remainder takes the divisor's sign."""
+    a = np.asarray(a, F32)
+    return (np.remainder(a + PI, TWO_PI).astype(F32) - PI).astype(F32)
+
+
+def linspace_f32(start, end, steps):
+    """torch.linspace on CPU for fp32: symmetric two-sided formula (start + i*step | end - (steps-1-i)*step),
+    fp32 step, each element one fused multiply-add (emulated exactly through float64)."""
+    start, end = F32(start), F32(end)
+    step = np.float64(F32((end - start) / F32(steps - 1)))
+    i = np.arange(steps)
+    lo = (np.float64(start) + step * i).astype(F32)
+    hi = (np.float64(end) - step * (steps - 1 - i)).astype(F32)
+    return np.where(i < steps // 2, lo, hi).astype(F32)
+
+
+def sigmoid(x):
+    x = np.asarray(x, F32)
+    return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# ONF (occupancy neural field)
+class OnfConfig(object):
+    """Shape/normalisation of an ONF instance: nfop/onf_model.py:8-31."""
+
+    def __init__(self, mean=0.0, sigma=1.0, use_cos=True, bias=True, angle_encoding=True, angle_dim=10):
+        self.mean, self.sigma = float(mean), float(sigma)
+        self.use_cos, self.bias, self.angle_encoding = bool(use_cos), bool(bias), bool(angle_encoding)
+        self.angle_dim = int(angle_dim) if angle_encoding else 0
+        self.n_enc = 200 if use_cos else 100          # encoding_layer outputs (onf_model.py:15,29)
+        self.n_ang = 2 * self.angle_dim                # AngleEncoder.encoding_dimension (angle_encoder.py:20-22)
+        self.feature_dim = self.n_enc + self.n_ang
+        self.point_dim = 3 if angle_encoding else 2
+
+    @classmethod
+    def from_vector(cls, v):
+        """[mean, sigma, use_cos, bias, angle_encoding] as stored in the golden fixtures."""
+        return cls(v[0], v[1], bool(v[2]), bool(v[3]), bool(v[4]))
+
+    def layout(self):
+        """(name, shape) in `state_dict()` order -- the flat parameter buffer order."""
+        f, h = self.feature_dim, HIDDEN
+        out = []
+        if self.angle_encoding:
+            out += [("ang_b", (self.n_ang,)), ("ang_f", (self.n_ang,))]
+        out += [("w1", (h, f)), ("b1", (h,)), ("w2", (h, h)), ("b2", (h,)), ("w3", (1, h + f)), ("b3", (1,)),
+                ("we", (self.n_enc, 2))]
+        if self.bias:
+            out += [("be", (self.n_enc,))]
+        return out
+
+    def n_params(self):
+        return int(sum(int(np.prod(s)) for _, s in self.layout()))
+
+
+def unpack_params(flat, cfg):
+    flat = np.asarray(flat, F32)
+    assert flat.size == cfg.n_params(), (flat.size, cfg.n_params())
+    out, o = {}, 0
+    for name, shape in cfg.layout():
+        n = int(np.prod(shape))
+        out[name] = flat[o:o + n].reshape(shape)
+        o += n
+    if not cfg.bias:
+        out["be"] = np.zeros(cfg.n_enc, F32)
+    return out
+
+
+def pack_params(p, cfg):
+    return np.concatenate([np.asarray(p[name], F32).reshape(-1) for name, _ in cfg.layout()]).astype(F32)
+
+
+def _onf_forward_cache(p, cfg, x):
+    """nfop/onf_model.py:33-50, nfop/angle_encoder.py:15-18."""
+    x = np.asarray(x, F32)
+    u = ((x[:, :2] - F32(cfg.mean)) / F32(cfg.sigma)).astype(F32)
+    e = (u @ p["we"].T + p["be"]).astype(F32)
+    if cfg.use_cos:
+        s = np.concatenate([np.sin(e[:, :100]), np.cos(e[:, 100:])], 1).astype(F32)
+    else:
+        s = np.sin(e).astype(F32)
+    c = {"u": u, "e": e}
+    if cfg.angle_encoding:
+        d = cfg.angle_dim
+        z = ((x[:, 2:3] + p["ang_b"][None]) * p["ang_f"][None]).astype(F32)
+        code = np.concatenate([np.sin(z[:, :d]), np.cos(z[:, d:])], 1).astype(F32)
+        inp = np.concatenate([s, code], 1)
+        c["z"] = z
+    else:
+        inp = s
+    a1 = (inp @ p["w1"].T + p["b1"]).astype(F32)
+    h1 = np.maximum(a1, 0)
+    a2 = (h1 @ p["w2"].T + p["b2"]).astype(F32)
+    h2 = np.maximum(a2, 0)
+    logit = (np.concatenate([h2, inp], 1) @ p["w3"].T + p["b3"]).astype(F32)[:, 0]
+    c.update(inp=inp, a1=a1, h1=h1, a2=a2, h2=h2)
+    return logit, c
+
+
+def onf_forward(flat, cfg, x):
+    return _onf_forward_cache(unpack_params(flat, cfg), cfg, x)[0]
+
+
+def _onf_input_backward(p, cfg, x, c, rho=None):
+    """Closed-form d logit / d(x, y[, theta]).  `rho` = optional upstream per point."""
+    h = HIDDEN
+    w3 = p["w3"][0]
+    dh2 = (w3[None, :h] * (c["a2"] > 0)).astype(F32)
+    dh1 = ((dh2 @ p["w2"]) * (c["a1"] > 0)).astype(F32)
+    din = (dh1 @ p["w1"] + w3[None, h:]).astype(F32)
+    e = c["e"]
+    if cfg.use_cos:
+        de = np.concatenate([din[:, :100] * np.cos(e[:, :100]), -din[:, 100:200] * np.sin(e[:, 100:])], 1)
+    else:
+        de = din[:, :100] * np.cos(e)
+    de = de.astype(F32)
+    gxy = ((de @ p["we"]) / F32(cfg.sigma)).astype(F32)
+    out = {"dh2": dh2, "dh1": dh1, "din": din, "de": de}
+    if cfg.angle_encoding:
+        d = cfg.angle_dim
+        z, f = c["z"], p["ang_f"]
+        dz = np.concatenate([din[:, cfg.n_enc:cfg.n_enc + d] * np.cos(z[:, :d]),
+                             -din[:, cfg.n_enc + d:] * np.sin(z[:, d:])], 1).astype(F32)
+        gth = np.sum(dz * f[None], 1, dtype=F32)
+        out["dz"] = dz
+        g = np.concatenate([gxy, gth[:, None]], 1)
+    else:
+        g = gxy
+    return g.astype(F32), out
+
+
+def onf_forward_grad(flat, cfg, x):
+    """-> (logit[P], dlogit/dx [P, point_dim])."""
+    p = unpack_params(flat, cfg)
+    logit, c = _onf_forward_cache(p, cfg, x)
+    g, _ = _onf_input_backward(p, cfg, x, c)
+    return logit, g
+
+
+def onf_train_grads(flat, cfg, x, labels):
+    """BCE-with-logits (mean) loss and flat parameter gradient: nfop/nerf_opt_planner.py:83-89 (all parameters
+    incl. the angle frequencies receive gradients because of `requires_grad_(True)`, SURVEY quirk v)."""
+    p = unpack_params(flat, cfg)
+    x = np.asarray(x, F32)
+    y = np.asarray(labels, F32)
+    P = x.shape[0]
+    logit, c = _onf_forward_cache(p, cfg, x)
+    loss = np.mean(np.maximum(logit, 0) - logit * y + np.log1p(np.exp(-np.abs(logit))), dtype=np.float64)
+    rho = ((sigmoid(logit) - y) / F32(P)).astype(F32)
+    h = HIDDEN
+    w3 = p["w3"][0]
+    g = {}
+    cat = np.concatenate([c["h2"], c["inp"]], 1)
+    g["w3"] = (rho[None] @ cat).astype(F32)
+    g["b3"] = np.asarray([rho.sum(dtype=F32)], F32)
+    dh2 = (rho[:, None] * w3[None, :h] * (c["a2"] > 0)).astype(F32)
+    g["w2"] = (dh2.T @ c["h1"]).astype(F32)
+    g["b2"] = dh2.sum(0, dtype=F32)
+    dh1 = ((dh2 @ p["w2"]) * (c["a1"] > 0)).astype(F32)
+    g["w1"] = (dh1.T @ c["inp"]).astype(F32)
+    g["b1"] = dh1.sum(0, dtype=F32)
+    din = (dh1 @ p["w1"] + rho[:, None] * w3[None, h:]).astype(F32)
+    e = c["e"]
+    if cfg.use_cos:
+        de = np.concatenate([din[:, :100] * np.cos(e[:, :100]), -din[:, 100:200] * np.sin(e[:, 100:])], 1)
+    else:
+        de = din[:, :100] * np.cos(e)
+    de = de.astype(F32)
+    g["we"] = (de.T @ c["u"]).astype(F32)
+    g["be"] = de.sum(0, dtype=F32)
+    if cfg.angle_encoding:
+        d = cfg.angle_dim
+        z = c["z"]
+        dz = np.concatenate([din[:, cfg.n_enc:cfg.n_enc + d] * np.cos(z[:, :d]),
+                             -din[:, cfg.n_enc + d:] * np.sin(z[:, d:])], 1).astype(F32)
+        g["ang_b"] = (dz * p["ang_f"][None]).sum(0, dtype=F32)
+        g["ang_f"] = (dz * (x[:, 2:3] + p["ang_b"][None])).sum(0, dtype=F32)
+    return F32(loss), logit, pack_params(g, cfg)
+
+
+def adam_update(param, grad, m, v, step, lr, beta1, beta2, eps):
+    """torch.optim.Adam single-tensor path (torch 2.x): lerp / addcmul / addcdiv.  `step` is the 1-based count
+    AFTER increment.  Scalars are formed in Python doubles and applied in fp32, as torch does."""
+    param, grad, m, v = (np.asarray(a, F32) for a in (param, grad, m, v))
+    m = (m + (grad - m) * F32(1 - beta1)).astype(F32)
+    v = (v * F32(beta2) + (grad * grad) * F32(1 - beta2)).astype(F32)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    step_size = lr / bc1
+    denom = (np.sqrt(v) / F32(bc2 ** 0.5) + F32(eps)).astype(F32)
+    param = (param - F32(step_size) * (m / denom)).astype(F32)
+    return param, m, v
+
+
+# ----------------------------------------------------------------------------------------------------------
+# trajectory terms (SE(2), ConstrainedNERFOptPlanner)
+class Hyper(object):
+    """Scalar hyper-parameters of ConstrainedNERFOptPlanner (nfop/constrained_nerf_opt_planner.py:13-40)."""
+
+    def __init__(self, collision_weight=1.0, angle_weight=0.5, constraint_deltas_weight=20.0, multipliers_lr=0.1,
+                 collision_multipliers_lr=1e-3, boundary_weight=1.0, collision_beta=1.0,
+                 direction_delta_weight=0.0, lr=1e-2, beta1=0.9, beta2=0.9, eps=1e-8,
+                 bounds=(-0.1, 3.1, -0.1, 3.1)):
+        self.collision_weight = float(collision_weight)
+        self.angle_weight = float(angle_weight)
+        self.constraint_deltas_weight = float(constraint_deltas_weight)
+        self.multipliers_lr = float(multipliers_lr)
+        self.collision_multipliers_lr = float(collision_multipliers_lr)
+        self.boundary_weight = float(boundary_weight)
+        self.collision_beta = float(collision_beta)
+        self.direction_delta_weight = float(direction_delta_weight)
+        self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
+        self.bounds = tuple(float(b) for b in bounds)
+
+    @classmethod
+    def from_npz(cls, z, prefix="hp_"):
+        kw = {}
+        for k in ("collision_weight", "angle_weight", "constraint_deltas_weight", "multipliers_lr",
+                  "collision_multipliers_lr", "boundary_weight", "collision_beta", "direction_delta_weight",
+                  "lr", "beta1", "beta2", "eps"):
+            kw[k] = float(z[prefix + k])
+        kw["bounds"] = tuple(float(b) for b in z[prefix + "bounds"])
+        return cls(**kw)
+
+
+def full_trajectory(traj, start, goal):
+    """nfop/nerf_opt_planner.py:73-74 with a batch axis: [B,N,D] + [B,D] -> [B,N+2,D]."""
+    return np.concatenate([start[:, None], traj, goal[:, None]], 1).astype(F32)
+
+
+def sample_collision_points(traj, t):
+    """nfop/constrained_nerf_opt_planner.py:78-81: between consecutive INTERIOR waypoints, theta wrapped."""
+    d = (traj[:, :-1] - traj[:, 1:]).astype(F32)
+    d[..., 2] = wrap_angle(d[..., 2])
+    return (traj[:, 1:] + t[..., None] * d).astype(F32)
+
+
+def trajectory_loss_terms(traj, start, goal, lam, cm, t, logit, dlogit, hp):
+    """All loss terms of constrained:76-130 + nerf:171-176 and their closed-form gradients.
+
+    traj [B,N,3]; start/goal [B,3]; lam [B,N+1]; cm [B,N]; t [B,N-1]; logit [B,N-1]; dlogit [B,N-1,3]
+    (ONF evaluated at `sample_collision_points`).  Returns dict of per-trajectory terms and gradients."""
+    traj, start, goal, lam, cm, t = (np.asarray(a, F32) for a in (traj, start, goal, lam, cm, t))
+    B, N, _ = traj.shape
+    q = full_trajectory(traj, start, goal)
+    G = np.zeros_like(q)
+    aw = F32(hp.angle_weight)
+
+    # A7 distance (constrained:120-130): raw theta deltas + constant winding correction on the last segment
+    delta = (q[:, 1:] - q[:, :-1]).astype(F32)
+    wrapped = wrap_angle(delta[..., 2])
+    angle_sum = (wrapped.sum(1, dtype=F32) - q[:, -1, 2] + q[:, 0, 2]).astype(F32)
+    delta[:, -1, 2] += angle_sum
+    delta[..., 2] *= aw
+    l_dist = np.sum(delta.astype(F32) ** 2, axis=(1, 2), dtype=F32)
+    gd = (F32(2) * delta).astype(F32)
+    gd[..., 2] *= aw
+    G[:, 1:] += gd
+    G[:, :-1] -= gd
+
+    # A5 non-holonomic (constrained:102-109)
+    dx = (q[:, 1:, 0] - q[:, :-1, 0]).astype(F32)
+    dy = (q[:, 1:, 1] - q[:, :-1, 1]).astype(F32)
+    th = q[..., 2]
+    m = (th[:, :-1] + wrap_angle(th[:, 1:] - th[:, :-1]) / F32(2)).astype(F32)
+    sm, cmm = np.sin(m).astype(F32), np.cos(m).astype(F32)
+    c = (dx * sm - dy * cmm).astype(F32)
+    e = (dx * cmm + dy * sm).astype(F32)
+    l_lin = np.sum(lam * c, 1, dtype=F32)
+    l_c2 = np.sum(c * c, 1, dtype=F32)
+    g = (lam + F32(2 * hp.constraint_deltas_weight) * c).astype(F32)
+    G[:, 1:, 0] += g * sm
+    G[:, :-1, 0] -= g * sm
+    G[:, 1:, 1] -= g * cmm
+    G[:, :-1, 1] += g * cmm
+    G[:, :-1, 2] += g * e / F32(2)
+    G[:, 1:, 2] += g * e / F32(2)
+
+    # A6 direction / forward-only (constrained:111-118, :93, :98)
+    mp = (th[:, :-1] + wrap_angle(th[:, :-1] - th[:, 1:]) / F32(2)).astype(F32)
+    smp, cmp_ = np.sin(mp).astype(F32), np.cos(mp).astype(F32)
+    d = (-(cmp_ * dx + smp * dy)).astype(F32)
+    r = np.where(d > 0, d, F32(0)).astype(F32)
+    l_dir = np.sum(r * r, 1, dtype=F32)
+    hh = (F32(2 * hp.direction_delta_weight) * r).astype(F32)
+    k = (smp * dx - cmp_ * dy).astype(F32)
+    G[:, 1:, 0] -= hh * cmp_
+    G[:, :-1, 0] += hh * cmp_
+    G[:, 1:, 1] -= hh * smp
+    G[:, :-1, 1] += hh * smp
+    G[:, :-1, 2] += F32(1.5) * hh * k
+    G[:, 1:, 2] -= F32(0.5) * hh * k
+
+    # A8 boundary (nerf:171-176), interior only
+    lo_x, hi_x, lo_y, hi_y = (F32(b) for b in hp.bounds)
+    x, y = traj[..., 0], traj[..., 1]
+    bx0, bx1 = np.maximum(lo_x - x, 0), np.maximum(x - hi_x, 0)
+    by0, by1 = np.maximum(lo_y - y, 0), np.maximum(y - hi_y, 0)
+    l_bnd = np.sum(bx0 ** 2 + bx1 ** 2 + by0 ** 2 + by1 ** 2, 1, dtype=F32)
+    wb = F32(2 * hp.boundary_weight)
+    G[:, 1:-1, 0] += wb * (bx1 - bx0)
+    G[:, 1:-1, 1] += wb * (by1 - by0)
+
+    # A4 collision (constrained:78-89)
+    beta = F32(hp.collision_beta)
+    bl = (logit * beta).astype(F32)
+    with np.errstate(over="ignore"):
+        z = np.exp(bl, dtype=F32)
+        sp = np.where(bl > 20, logit, np.log1p(z) / beta).astype(F32)
+        dsp = np.where(bl > 20, F32(1), z / (z + F32(1))).astype(F32)
+    th_l = np.tanh(logit).astype(F32)
+    cm_i = (cm[:, 1:] * (F32(1) - t) + cm[:, :-1] * t).astype(F32)
+    l_col = np.sum(sp, 1, dtype=F32)
+    l_cm = np.sum(cm_i * th_l, 1, dtype=F32)
+    gamma = (F32(hp.collision_weight) * dsp + cm_i * (F32(1) - th_l * th_l)).astype(F32)
+    gg = (gamma[..., None] * dlogit).astype(F32)
+    G[:, 1:-2] += t[..., None] * gg            # a = traj[:-1]  -> full indices 1..N-1
+    G[:, 2:-1] += (F32(1) - t)[..., None] * gg  # b = traj[1:]   -> full indices 2..N
+    g_cm = np.zeros_like(cm)
+    g_cm[:, 1:] += (F32(1) - t) * th_l
+    g_cm[:, :-1] += t * th_l
+
+    total = (l_dist + F32(hp.collision_weight) * l_col + l_lin + F32(hp.constraint_deltas_weight) * l_c2
+             + F32(hp.boundary_weight) * l_bnd + l_cm + F32(hp.direction_delta_weight) * l_dir).astype(F32)
+    return dict(total=total, l_dist=l_dist, l_col=l_col, l_lin=l_lin, l_c2=l_c2, l_bnd=l_bnd, l_cm=l_cm,
+                l_dir=l_dir, c=c, d=d, g_traj=G[:, 1:-1].astype(F32), g_lam=c, g_cm=g_cm.astype(F32))
+
+
+def calculate_inv_hessian(n, w):
+    """nfop/nerf_opt_planner.py:45-58: float64 inverse of w*tridiag(-2,4,-2)+I, rounded to fp32."""
+    k = np.zeros((n, n), np.float32)
+    i = np.arange(n)
+    k[i, i] = 4
+    k[i[1:], i[:-1]] = -2
+    k[i[:-1], i[1:]] = -2
+    h = w * k + np.eye(n)
+    return np.linalg.inv(h).astype(F32)
+
+
+def optimize_trajectory(traj, start, goal, lam, cm, adam_m, adam_v, adam_step, t, onf_flat, cfg, hp, hinv):
+    """One `_optimize_trajectory` (nerf:143-155 + constrained:63-74) for a batch.  `adam_step` = count BEFORE
+    this step.  Returns new (traj, lam, cm, m, v) and the loss terms."""
+    B, N, _ = traj.shape
+    pts = sample_collision_points(np.asarray(traj, F32), np.asarray(t, F32))
+    logit, dl = onf_forward_grad(onf_flat, cfg, pts.reshape(-1, 3))
+    terms = trajectory_loss_terms(traj, start, goal, lam, cm, t, logit.reshape(B, N - 1), dl.reshape(B, N - 1, 3), hp)
+    g = np.einsum("ij,bjd->bid", hinv, terms["g_traj"]).astype(F32)
+    new_traj, m, v = adam_update(traj, g, adam_m, adam_v, adam_step + 1, hp.lr, hp.beta1, hp.beta2, hp.eps)
+    new_lam = (np.asarray(lam, F32) + F32(hp.multipliers_lr) * terms["g_lam"]).astype(F32)
+    new_cm = (np.asarray(cm, F32) + F32(hp.collision_multipliers_lr) * terms["g_cm"]).astype(F32)
+    new_cm = np.where(new_cm > 0, new_cm, F32(0)).astype(F32)
+    return new_traj, new_lam, new_cm, m, v, terms
+
+
+def _searchsorted_left(cdf, u):
+    return np.stack([np.searchsorted(cdf[b], u, side="left") for b in range(cdf.shape[0])])
+
+
+def reparametrize(traj, start, goal, lam=None, cm=None):
+    """Arc-length (xy) reparametrisation: constrained:132-171 (SE(2), with multipliers) / nerf:224-244 (2-D)."""
+    traj = np.asarray(traj, F32)
+    B, N, D = traj.shape
+    q = full_trajectory(traj, np.asarray(start, F32), np.asarray(goal, F32))
+    seg = q[:, 1:, :2] - q[:, :-1, :2]
+    dist = np.sqrt(np.sum(seg * seg, 2, dtype=F32)).astype(F32)
+    nd = (dist / dist.sum(1, dtype=F32)[:, None]).astype(F32)
+    cdf = np.concatenate([np.zeros((B, 1), F32), np.cumsum(nd, 1, dtype=F32)], 1)
+    u = linspace_f32(0, 1, N + 2)[1:-1]
+    idx = _searchsorted_left(cdf, u)
+    ia = np.where(idx > N + 1, N + 1, idx)
+    ib = np.where(idx - 1 < 0, 0, idx - 1)
+    ca = np.take_along_axis(cdf, ia, 1)
+    cb = np.take_along_axis(cdf, ib, 1)
+    den = (ca - cb).astype(F32)
+    den = np.where(den < F32(1e-5), F32(1e-5), den)
+    tau = ((u[None] - cb) / den).astype(F32)
+    qa = np.take_along_axis(q, ia[..., None], 1)
+    qb = np.take_along_axis(q, ib[..., None], 1)
+    out = np.empty_like(traj)
+    if D == 2:
+        out[:] = (F32(1) - tau)[..., None] * qb + tau[..., None] * qa
+        return out.astype(F32)
+    out[..., :2] = (F32(1) - tau)[..., None] * qb[..., :2] + tau[..., None] * qa[..., :2]
+    out[..., 2] = qb[..., 2] + tau * wrap_angle(qa[..., 2] - qb[..., 2])
+    cm = np.asarray(cm, F32)
+    lam = np.asarray(lam, F32)
+    cmf = np.concatenate([np.zeros((B, 1), F32), cm, np.zeros((B, 1), F32)], 1)
+    new_cm = ((F32(1) - tau) * np.take_along_axis(cmf, ib, 1) + tau * np.take_along_axis(cmf, ia, 1)).astype(F32)
+    lf = np.concatenate([lam[:, :1], (lam[:, :-1] + lam[:, 1:]) / F32(2), lam[:, -1:]], 1).astype(F32)
+    li = ((F32(1) - tau) * np.take_along_axis(lf, ib, 1) + tau * np.take_along_axis(lf, ia, 1)).astype(F32)
+    new_lam = np.concatenate([li[:, :1], (li[:, :-1] + li[:, 1:]) / F32(2), li[:, -1:]], 1).astype(F32)
+    return out.astype(F32), new_lam, new_cm
+
+
+def planner_step(state, t, onf_flat, cfg, hp, hinv, reparam_freq=10):
+    """One frozen-ONF `step()` (nerf:60-71): trajectory optimisation, then reparametrisation when
+    `step_count % reparam_freq == 0`, then step_count += 1.  `state` is a dict updated in place."""
+    tr, lam, cm, m, v, terms = optimize_trajectory(state["traj"], state["start"], state["goal"], state["lam"],
+                                                   state["cm"], state["adam_m"], state["adam_v"],
+                                                   state["adam_step"], t, onf_flat, cfg, hp, hinv)
+    state.update(traj=tr, lam=lam, cm=cm, adam_m=m, adam_v=v, adam_step=state["adam_step"] + 1)
+    if state["step_count"] % reparam_freq == 0:
+        tr, lam, cm = reparametrize(state["traj"], state["start"], state["goal"], state["lam"], state["cm"])
+        state.update(traj=tr, lam=lam, cm=cm)
+    state["step_count"] += 1
+    return terms
+
+
+# ----------------------------------------------------------------------------------------------------------
+# 2-D planner (NERFOptPlanner)
+def trajectory_loss_2d(traj, start, goal, t, logit, dlogit, collision_weight):
+    """nfop/nerf_opt_planner.py:157-169 with p = traj[1:](1-t) + traj[:-1] t (:113-117)."""
+    traj = np.asarray(traj, F32)
+    q = full_trajectory(traj, np.asarray(start, F32), np.asarray(goal, F32))
+    G = np.zeros_like(q)
+    delta = (q[:, 1:] - q[:, :-1]).astype(F32)
+    l_dist = np.sum(delta ** 2, axis=(1, 2), dtype=F32)
+    G[:, 1:] += F32(2) * delta
+    G[:, :-1] -= F32(2) * delta
+    with np.errstate(over="ignore"):
+        z = np.exp(logit, dtype=F32)
+        sp = np.where(logit > 20, logit, np.log1p(z)).astype(F32)
+        dsp = np.where(logit > 20, F32(1), z / (z + F32(1))).astype(F32)
+    l_col = np.sum(sp, 1, dtype=F32)
+    gg = (F32(collision_weight) * dsp[..., None] * dlogit).astype(F32)
+    G[:, 1:-2] += t[..., None] * gg
+    G[:, 2:-1] += (F32(1) - t)[..., None] * gg
+    total = (l_dist + l_col * F32(collision_weight)).astype(F32)
+    return dict(total=total, l_dist=l_dist, l_col=l_col, g_traj=G[:, 1:-1].astype(F32))
+
+
+def sample_collision_points_2d(traj, t):
+    return (traj[:, 1:] * (F32(1) - t)[..., None] + traj[:, :-1] * t[..., None]).astype(F32)
+
+
+def optimize_trajectory_2d(traj, start, goal, adam_m, adam_v, adam_step, t, onf_flat, cfg, collision_weight,
+                           lr, beta1, beta2, eps, hinv):
+    B, N, _ = traj.shape
+    pts = sample_collision_points_2d(np.asarray(traj, F32), np.asarray(t, F32))
+    logit, dl = onf_forward_grad(onf_flat, cfg, pts.reshape(-1, 2))
+    terms = trajectory_loss_2d(traj, start, goal, t, logit.reshape(B, N - 1), dl.reshape(B, N - 1, 2), collision_weight)
+    g = np.einsum("ij,bjd->bid", hinv, terms["g_traj"]).astype(F32)
+    new_traj, m, v = adam_update(traj, g, adam_m, adam_v, adam_step + 1, lr, beta1, beta2, eps)
+    return new_traj, m, v, terms
+
+
+# ----------------------------------------------------------------------------------------------------------
+# ground-truth checkers and initialiser (host-side rows of SURVEY section 8: A14, section 8(f) rank 2)
+def check_boundaries(xy, boundaries):
+    """nfop/collision_checker/collision_checker.py:12-19."""
+    if boundaries is None:
+        return np.zeros(len(xy), bool)
+    return (xy[:, 0] > boundaries[1]) | (xy[:, 0] < boundaries[0]) | (xy[:, 1] > boundaries[3]) | (xy[:, 1] < boundaries[2])
+
+
+def circle_check(xy, obstacles, radius, boundaries=None):
+    """nfop/collision_checker/circle_collision_checker.py:11-14."""
+    d = np.linalg.norm(xy[None] - obstacles[:, None], axis=2)
+    return np.any(d < radius, axis=0) | check_boundaries(xy, boundaries)
+
+
+def rectangle_check(poses, obstacles, box, boundaries=None):
+    """nfop/collision_checker/rectangle_collision_checker.py:11-26: obstacle points into the robot frame."""
+    x, y, th = poses[:, 0], poses[:, 1], poses[:, 2]
+    c, s = np.cos(th), np.sin(th)
+    ox, oy = obstacles[:, 0][None], obstacles[:, 1][None]
+    rx = c[:, None] * (ox - x[:, None]) + s[:, None] * (oy - y[:, None])
+    ry = -s[:, None] * (ox - x[:, None]) + c[:, None] * (oy - y[:, None])
+    inside = (rx > box[0]) & (rx < box[1]) & (ry > box[2]) & (ry < box[3])
+    return np.any(inside, 1) | check_boundaries(poses[:, :2], boundaries)
+
+
+def initialize_trajectory(start, goal, n):
+    """nfop/trajectory_initializer.py:12-29: straight line in xy, theta along the wrapped shortest rotation."""
+    start, goal = np.asarray(start, F32), np.asarray(goal, F32)
+    out = np.zeros((n, 3), F32)
+    out[:, 0] = linspace_f32(start[0], goal[0], n + 2)[1:-1]
+    out[:, 1] = linspace_f32(start[1], goal[1], n + 2)[1:-1]
+    ga = F32(wrap_angle(goal[2] - start[2]) + start[2])
+    out[:, 2] = linspace_f32(start[2], ga, n + 2)[1:-1]
+    return out
