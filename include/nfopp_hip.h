@@ -1,0 +1,136 @@
+/*
+ * nfopp_hip.h -- C ABI of the MI355X-native NFOPP inner loop (libnfopp_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of MisterMap/pytorch-motion-planner: the per-step work of
+ * NERFOptPlanner / ConstrainedNERFOptPlanner `.step()`.  The reference has no native interface for this path
+ * (it is PyTorch-CPU eager + autograd); each entry point below replaces the PyTorch op sequence cited next to
+ * it (file:line under the reference root, `nfop/` = neural_field_optimal_planner/).  All pointers named *_dev are
+ * DEVICE pointers (HIP, gfx950) to contiguous fp32 row-major arrays; sizes are element counts unless they say
+ * bytes; `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on `stream`.
+ * Every function returns 0 on success and a negative nfopp_status otherwise; nfopp_last_error() describes the
+ * last failure of the calling thread.  No torch types, no ownership transfer: buffers are borrowed for the call.
+ *
+ * A batch of B trajectories is B independent reference problems that share one ONF (occupancy neural field).
+ */
+#ifndef NFOPP_HIP_H
+#define NFOPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFOPP_ABI_VERSION 1
+#define NFOPP_HIDDEN 100 /* width of both hidden layers, nfop/onf_model.py:18-23 */
+
+typedef enum nfopp_status {
+  NFOPP_OK = 0,
+  NFOPP_ERR_ARG = -1,     /* bad shape / null pointer / unsupported configuration */
+  NFOPP_ERR_HIP = -2,     /* HIP runtime error (message holds hipGetErrorString) */
+  NFOPP_ERR_NO_DEVICE = -3
+} nfopp_status;
+
+/* Shape and normalisation of an ONF instance: nfop/onf_model.py:8-31.
+ * The parameter buffer is ONE flat fp32 array in `state_dict()` order:
+ *   [_angle_encoder._biases (2*angle_dim), _angle_encoder._frequencies (2*angle_dim)]   if angle_dim > 0
+ *   mlp.0.weight [100, F], mlp.0.bias [100], mlp.2.weight [100,100], mlp.2.bias [100],
+ *   mlp2.0.weight [1, 100+F], mlp2.0.bias [1], encoding_layer.weight [E, 2], [encoding_layer.bias [E]] if has_bias
+ * with E = use_cos ? 200 : 100 and F = E + 2*angle_dim (220 for every shipped script). */
+typedef struct nfopp_onf_config {
+  float mean;         /* nfop/onf_model.py:38  x = (x - mean) / sigma */
+  float sigma;
+  int32_t use_cos;    /* 1: sin on the first 100 encodings, cos on the next 100 (onf_model.py:40-41) */
+  int32_t has_bias;   /* encoding_layer bias present */
+  int32_t angle_dim;  /* 0 = no AngleEncoder (2-D points), 10 = nfop/angle_encoder.py default */
+} nfopp_onf_config;
+
+/* Scalars of one trajectory optimisation step.  SE(2) terms: nfop/constrained_nerf_opt_planner.py:76-130,
+ * boundary nfop/nerf_opt_planner.py:171-176, Adam = torch.optim.Adam single-tensor path, multiplier ascent
+ * constrained:66-73.  adam_step_size = lr / (1 - beta1^k), adam_bc2_sqrt = sqrt(1 - beta2^k), both formed by the
+ * caller in double precision for the 1-based step count k, exactly as torch does; adam_omb1/2 = 1 - beta1/2
+ * likewise rounded from double (fp32(1 - 0.9) != 1.0f - 0.9f). */
+typedef struct nfopp_traj_hyper {
+  float collision_weight;
+  float angle_weight;
+  float constraint_deltas_weight;
+  float multipliers_lr;
+  float collision_multipliers_lr;
+  float boundary_weight;
+  float collision_beta;
+  float direction_delta_weight;
+  float bounds[4];          /* xmin, xmax, ymin, ymax */
+  float adam_beta2, adam_omb1, adam_omb2, adam_eps;
+  float adam_step_size, adam_bc2_sqrt;
+} nfopp_traj_hyper;
+
+#define NFOPP_NUM_TERMS 8 /* per-trajectory loss terms written by nfopp_traj_update (see below) */
+
+int nfopp_abi_version(void);
+const char* nfopp_last_error(void);
+/* number of visible HIP devices (0 when none / no driver); never fails */
+int nfopp_device_count(void);
+/* number of fp32 parameters of an ONF with this configuration (33161 for the shipped one), <0 on bad config */
+int64_t nfopp_onf_param_count(const nfopp_onf_config* cfg);
+
+/* ONF forward + input gradient at explicit points.  Replaces `ONF.forward` (nfop/onf_model.py:33-50,
+ * nfop/angle_encoder.py:15-18) followed by autograd w.r.t. the input.
+ *   points_dev [P, point_dim]  point_dim = 3 (x, y, theta) when angle_dim > 0, else 2
+ *   out4_dev   [P, 4]          logit, dlogit/dx, dlogit/dy, dlogit/dtheta (0 for 2-D fields) */
+int nfopp_onf_eval_points(const nfopp_onf_config* cfg, const float* params_dev, const float* points_dev,
+                          int64_t n_points, float* out4_dev, void* stream);
+
+/* Fused collision-point sampling + ONF forward + input gradient along a batch of trajectories: the ONF part
+ * of `trajectory_loss` (constrained:78-85 for D = 3, nfop/nerf_opt_planner.py:113-117,157-169 for D = 2).
+ *   traj_dev [B, N, D]   interior waypoints;  sample j of trajectory b lies between waypoints j and j+1
+ *   t_dev    [B, N-1]    t_mode 0: read (injected draws);  t_mode 1: drawn here with Philox4x32-10
+ *                        (key = seed, counter = (global sample index, rng_offset)) and WRITTEN for the
+ *                        update kernel;  traj_index_offset = global index of trajectory 0 (multi-GPU shards
+ *                        draw the same numbers as a single-GPU run)
+ *   out4_dev [B, N-1, 4] as nfopp_onf_eval_points */
+int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const float* params_dev, const float* traj_dev,
+                              int64_t batch, int32_t n_waypoints, int32_t dim, float* t_dev, int32_t t_mode,
+                              uint64_t seed, uint64_t rng_offset, int64_t traj_index_offset, float* out4_dev,
+                              void* stream);
+
+/* One `_optimize_trajectory` for every trajectory of the batch, given the ONF outputs at its samples:
+ * loss terms + closed-form gradients (constrained:87-130, nerf:171-176), g <- H^-1 g (nerf:151), Adam
+ * (nerf:154), multiplier ascent + clamp (constrained:66-73).  State arrays are updated IN PLACE.
+ *   traj_dev [B,N,D], start_dev/goal_dev [B,D], lam_dev [B,N+1], cm_dev [B,N] (both NULL for D = 2),
+ *   adam_m_dev/adam_v_dev [B,N,D], t_dev [B,N-1], onf_out4_dev [B,N-1,4]
+ *   hinv_band_dev [2*half_width+1, N]: band of the reference's fp32 inverse Hessian (nerf:45-48), transposed so
+ *       that entry [k][i] = Hinv[i][i + k - half_width] (0 outside the matrix)
+ *   terms_dev [B, 8] or NULL: total, distance, sum softplus, sum lam*c, sum c^2, boundary, sum cm*tanh, sum relu(d)^2 */
+int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int32_t n_waypoints, int32_t dim,
+                      float* traj_dev, const float* start_dev, const float* goal_dev, float* lam_dev,
+                      float* cm_dev, float* adam_m_dev, float* adam_v_dev, const float* t_dev,
+                      const float* onf_out4_dev, const float* hinv_band_dev, int32_t half_width,
+                      float* terms_dev, void* stream);
+
+/* Arc-length reparametrisation (constrained:132-171 for D = 3 incl. multipliers; nerf:224-244 for D = 2).
+ *   u_dev [N] = torch.linspace(0, 1, N+2)[1:-1] (formed by the caller so its rounding is the reference's) */
+int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t dim, float* traj_dev,
+                        const float* start_dev, const float* goal_dev, float* lam_dev, float* cm_dev,
+                        const float* u_dev, void* stream);
+
+/* ONF fitting step, gradient part: BCE-with-logits (mean over ALL samples of the job) and its gradient w.r.t.
+ * every parameter incl. the angle frequencies (nfop/nerf_opt_planner.py:83-89).
+ *   samples_dev [P, point_dim], labels_dev [P] (0/1), inv_count = 1 / (global sample count)
+ *   grad_dev [n_params + 2]: flat gradient in parameter order, then sum of per-sample losses * inv_count, then P
+ *   workspace: nfopp_onf_train_workspace_bytes(cfg, P) bytes of device scratch
+ * Reductions run in a fixed order (no float atomics): results are bitwise reproducible. */
+size_t nfopp_onf_train_workspace_bytes(const nfopp_onf_config* cfg, int64_t n_samples);
+int nfopp_onf_train_grad(const nfopp_onf_config* cfg, const float* params_dev, const float* samples_dev,
+                         const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam single-tensor update on a flat buffer (used for the ONF weights after the gradient
+ * all-reduce): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps). */
+int nfopp_adam_step(float* param_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, float beta2,
+                    float omb1, float omb2, float eps, float step_size, float bc2_sqrt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFOPP_HIP_H */

@@ -1,0 +1,121 @@
+// Shared host/device helpers of libnfopp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "nfopp_hip.h"
+
+namespace nfopp {
+
+// ---- error plumbing (host) -------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define NFOPP_REQUIRE(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::nfopp::set_error(__VA_ARGS__);    \
+      return NFOPP_ERR_ARG;               \
+    }                                     \
+  } while (0)
+
+#define NFOPP_HIP(call)                                          \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) return ::nfopp::hip_fail(e__, #call); \
+  } while (0)
+
+// ---- ONF parameter buffer geometry (state_dict order, include/nfopp_hip.h) --------------------------------------
+struct OnfGeom {
+  int n_enc, n_sin, ang_dim, n_ang, fin, point_dim;
+  int off_ang_b, off_ang_f, off_w1, off_b1, off_w2, off_b2, off_w3, off_b3, off_we, off_be;  // -1 = absent
+  int n_params;
+  float mean, sigma;
+};
+
+inline bool make_geom(const nfopp_onf_config* c, OnfGeom* g) {
+  if (!c) return false;
+  if (c->angle_dim < 0 || c->angle_dim > 16 || !(c->sigma != 0.0f)) return false;
+  g->n_enc = c->use_cos ? 200 : 100;
+  g->n_sin = 100;
+  g->ang_dim = c->angle_dim;
+  g->n_ang = 2 * c->angle_dim;
+  g->fin = g->n_enc + g->n_ang;
+  g->point_dim = c->angle_dim > 0 ? 3 : 2;
+  g->mean = c->mean;
+  g->sigma = c->sigma;
+  int o = 0;
+  g->off_ang_b = g->off_ang_f = -1;
+  if (g->n_ang) {
+    g->off_ang_b = o; o += g->n_ang;
+    g->off_ang_f = o; o += g->n_ang;
+  }
+  g->off_w1 = o; o += NFOPP_HIDDEN * g->fin;
+  g->off_b1 = o; o += NFOPP_HIDDEN;
+  g->off_w2 = o; o += NFOPP_HIDDEN * NFOPP_HIDDEN;
+  g->off_b2 = o; o += NFOPP_HIDDEN;
+  g->off_w3 = o; o += NFOPP_HIDDEN + g->fin;
+  g->off_b3 = o; o += 1;
+  g->off_we = o; o += 2 * g->n_enc;
+  g->off_be = -1;
+  if (c->has_bias) { g->off_be = o; o += g->n_enc; }
+  g->n_params = o;
+  return true;
+}
+
+// ---- device math shared by the kernels ---------------------------------------------------------------------------
+#define NFOPP_PI_F 3.14159274101257324f      /* fp32(pi)   */
+#define NFOPP_TWO_PI_F 6.28318548202514648f  /* fp32(2 pi) */
+
+// nfop/torch_math.py:5-7: (a + pi) % (2 pi) - pi, remainder with the divisor's sign, all in fp32.
+__device__ __forceinline__ float wrap_angle(float a) {
+  float r = fmodf(a + NFOPP_PI_F, NFOPP_TWO_PI_F);
+  if (r < 0.0f) r += NFOPP_TWO_PI_F;
+  return r - NFOPP_PI_F;
+}
+
+// sin(x + q*pi/2) for q in Z: 3-term Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials
+// (<= 1.5 ulp for |x| < 1e5; checked against float64 in tests/test_host_logic.py through an fp32 emulation).
+__device__ __forceinline__ float sin_quadrant(float x, int q) {
+  float j = rintf(x * 0.636619772f);
+  float r = fmaf(j, -1.57079601e+00f, x);
+  r = fmaf(j, -3.13916473e-07f, r);
+  r = fmaf(j, -5.39030253e-15f, r);
+  int n = (int)j + q;
+  float s = r * r;
+  float ps = 2.86567956e-6f;
+  ps = fmaf(ps, s, -1.98559923e-4f);
+  ps = fmaf(ps, s, 8.33338592e-3f);
+  ps = fmaf(ps, s, -1.66666672e-1f);
+  float sv = fmaf(ps, r * s, r);
+  float pc = 2.44677067e-5f;
+  pc = fmaf(pc, s, -1.38877297e-3f);
+  pc = fmaf(pc, s, 4.16666567e-2f);
+  pc = fmaf(pc, s, -5.0e-1f);
+  float cv = fmaf(pc, s, 1.0f);
+  float res = (n & 1) ? cv : sv;
+  return __int_as_float(__float_as_int(res) ^ ((n & 2) << 30));
+}
+
+// Philox4x32-10, first output word -> uniform [0,1) with 24 random bits (the same u32->float map torch uses).
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr_lo,
+                                                unsigned long long ctr_hi) {
+  unsigned int c0 = (unsigned int)ctr_lo, c1 = (unsigned int)(ctr_lo >> 32);
+  unsigned int c2 = (unsigned int)ctr_hi, c3 = (unsigned int)(ctr_hi >> 32);
+  unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * 5.9604644775390625e-08f;  // 2^-24
+}
+
+}  // namespace nfopp

@@ -1,0 +1,489 @@
+// Fused ONF forward + input-gradient kernel for gfx950 (MI355X), fp32 MFMA.
+//
+// Replaces (reference, PyTorch-CPU): ONF.forward nfop/onf_model.py:33-50 + AngleEncoder.forward
+// nfop/angle_encoder.py:15-18 + autograd w.r.t. the input, and -- in trajectory mode -- the sampling of the
+// collision points nfop/constrained_nerf_opt_planner.py:78-81 (SE(2)) / nfop/nerf_opt_planner.py:113-117 (2-D).
+//
+// Design (DESIGN.md section "K1"):
+//  * one persistent 512-thread workgroup per CU; the ONF weights are staged ONCE per workgroup into LDS as plain
+//    row-major images W1[100][S1], W2[100][129] (strides = 1 mod 32) and stay there for fwd AND bwd;
+//  * each wave owns NT tiles of 16 points.  Points sit on the MFMA N axis (lane & 15), features on M/K:
+//      D[feat][pt] += W[feat][k] * X[k][pt]        v_mfma_f32_16x16x4_f32, A = weights (ds_read_b32), B = activations
+//    The accumulator layout (row = 4*(lane>>4)+reg, col = lane&15) IS the B-operand layout of the next layer once
+//    the k index is permuted, so activations never leave registers between the four GEMMs
+//      L1: a1 = W1 in        L2: a2 = W2 relu(a1)       L2T: dh1 = W2^T dh2      L1T: din = W1^T dh1
+//    The permutations (layouts P for input features and h2, Q for h1 -- tools/emulate_mfma_layout.py) make every
+//    weight read of all four GEMMs bank-conflict-free from the SAME two LDS images;
+//  * input features sin/cos(W_e u + b_e), sin/cos((theta+b)f) are computed just-in-time as the L1 B operand and
+//    re-derived (shifted by a quadrant) in the L1T epilogue, so neither `in` nor `din` is ever stored.
+#include "common.h"
+
+namespace nfopp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H = NFOPP_HIDDEN;
+constexpr int HT = 7;     // hidden tiles of 16 (tile 6 carries features 96..99 in rows (g, r = 0))
+constexpr int S2 = 129;   // LDS row stride of W2 (floats), = 1 mod 32
+constexpr int THREADS = 512;
+constexpr int WAVES = THREADS / 64;
+constexpr int KSTEPS = 25;  // hidden k-steps: ks -> tile ks>>2, register ks&3 (tile 6 only register 0)
+
+struct OnfKernelArgs {
+  OnfGeom geom;
+  const float* params;
+  // explicit-point mode
+  const float* points;
+  // trajectory mode (points == nullptr)
+  const float* traj;
+  int n_way, dim;
+  float* t;
+  int t_mode;
+  unsigned long long seed, rng_offset;
+  long long traj_index_offset;
+  long long n_points;
+  float* out4;
+};
+
+template <int NKT>
+struct Lds {
+  // layout P spreads a pair of input tiles over a block of 32 features, so an odd NKT still indexes a full block
+  static constexpr int NF = 32 * ((NKT + 1) / 2);           // input-feature slots (>= fin, zero padded)
+  static constexpr int S1 = (NF > 128) ? 225 : 129;         // = 1 mod 32, > NF
+  static constexpr int W1 = 0;
+  static constexpr int W2 = W1 + H * S1;
+  static constexpr int FT = ((W2 + H * S2 + 3) / 4) * 4;  // feature table, 8 floats per input feature
+  static constexpr int B1 = FT + NF * 8;                  // 112 each, D-layout indexable (see fill)
+  static constexpr int B2 = B1 + 16 * HT;
+  static constexpr int W3A = B2 + 16 * HT;
+  static constexpr int W3B = W3A + 16 * HT;               // NF skip weights
+  static constexpr int TOTAL = W3B + NF;
+  static constexpr size_t BYTES = size_t(TOTAL) * 4;
+};
+
+__device__ __forceinline__ int base_p(int t) { return 32 * (t >> 1) + 8 * (t & 1); }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- stage the flat parameter buffer into LDS ---------------------------------------------------------------
+template <int NKT>
+__device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
+  using L = Lds<NKT>;
+  const OnfGeom& g = a.geom;
+  const float* P = a.params;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < H * L::S1; idx += THREADS) {
+    int row = idx / L::S1, col = idx - row * L::S1;
+    lds[L::W1 + idx] = col < g.fin ? P[g.off_w1 + row * g.fin + col] : 0.0f;
+  }
+  for (int idx = tid; idx < H * S2; idx += THREADS) {
+    int row = idx / S2, col = idx - row * S2;
+    lds[L::W2 + idx] = col < H ? P[g.off_w2 + row * H + col] : 0.0f;
+  }
+  for (int f = tid; f < L::NF; f += THREADS) {
+    float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, w3b = 0.f;
+    int flags = 0;  // bit0: cosine feature, bit1: angle feature
+    if (f < g.n_enc) {
+      wx = P[g.off_we + 2 * f];
+      wy = P[g.off_we + 2 * f + 1];
+      b = g.off_be >= 0 ? P[g.off_be + f] : 0.0f;
+      flags = (g.n_enc > g.n_sin && f >= g.n_sin) ? 1 : 0;
+      w3b = P[g.off_w3 + H + f];
+    } else if (f < g.fin) {
+      int k = f - g.n_enc;
+      b = P[g.off_ang_b + k];
+      fr = P[g.off_ang_f + k];
+      flags = 2 | (k >= g.ang_dim ? 1 : 0);
+      w3b = P[g.off_w3 + H + f];
+    }
+    float* e = lds + L::FT + 8 * f;
+    e[0] = wx; e[1] = wy; e[2] = b; e[3] = fr;
+    e[4] = __int_as_float(flags); e[5] = 0.f; e[6] = 0.f; e[7] = 0.f;
+    lds[L::W3B + f] = w3b;
+  }
+  // hidden-indexed vectors: entries 0..95 natural; entries 96 + 4g + r hold feature 96+g for r == 0, else 0
+  for (int k = tid; k < 16 * HT; k += THREADS) {
+    int h = k < 96 ? k : (((k - 96) & 3) == 0 ? 96 + ((k - 96) >> 2) : -1);
+    lds[L::B1 + k] = h >= 0 ? P[g.off_b1 + h] : 0.0f;
+    lds[L::B2 + k] = h >= 0 ? P[g.off_b2 + h] : 0.0f;
+    lds[L::W3A + k] = h >= 0 ? P[g.off_w3 + h] : 0.0f;
+  }
+}
+
+// argument of input feature described by table entry e0 = (wx, wy, b, fr) for the point (ux, uy, th)
+template <bool MAY_BE_ANGLE>
+__device__ __forceinline__ float feature_arg(const f32x4 e0, int flags, float ux, float uy, float th) {
+  float arg = fmaf(e0.x, ux, fmaf(e0.y, uy, e0.z));  // encoding_layer: W_e u + b_e (onf_model.py:39)
+  if (MAY_BE_ANGLE) {
+    float za = (th + e0.z) * e0.w;                   // (theta + b) * f (angle_encoder.py:16)
+    arg = (flags & 2) ? za : arg;
+  }
+  return arg;
+}
+
+template <int NKT, int NT>
+__global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernelArgs a) {
+  using L = Lds<NKT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds<NKT>(lds, a);
+  __syncthreads();
+
+  const OnfGeom& geo = a.geom;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4, gi = i >> 2, ri = i & 3;
+  const int colP = 16 * (g & 1) + 4 * (g >> 1), colQ = 8 * (g & 1) + 4 * (g >> 1);
+  const int rowposP = 16 * (gi & 1) + 4 * (gi >> 1) + ri, rowposQ = 8 * (gi & 1) + 4 * (gi >> 1) + ri;
+  // first input tile that can hold an angle feature (layout P puts feature f in tile pair f/32)
+  const int first_angle_kt = geo.n_ang ? 2 * (geo.n_enc / 32) : NKT;
+
+  const float* W1 = lds + L::W1;
+  const float* W2 = lds + L::W2;
+  const f32x4* FT = reinterpret_cast<const f32x4*>(lds + L::FT);
+  constexpr int S1 = L::S1;
+  constexpr int CH = WAVES * 16 * NT;
+  const long long n_chunks = (a.n_points + CH - 1) / CH;
+  const float b3 = a.params[geo.off_b3];
+
+  for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // ---------------------------------------------------------------- sample / load the wave's points
+    float ux[NT], uy[NT], th[NT];
+    long long pidx[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      long long p = chunk * CH + (wave * NT + tl) * 16 + i;
+      pidx[tl] = p;
+      if (p >= a.n_points) p = a.n_points - 1;
+      float x, y, ang = 0.f;
+      if (a.points) {
+        const float* q = a.points + p * geo.point_dim;
+        x = q[0]; y = q[1];
+        if (geo.point_dim == 3) ang = q[2];
+      } else {
+        const int nseg = a.n_way - 1;
+        long long b = p / nseg;
+        int j = (int)(p - b * nseg);
+        float tt;
+        if (a.t_mode == 0) {
+          tt = a.t[p];
+        } else {
+          unsigned long long gp = (unsigned long long)((a.traj_index_offset + b) * nseg + j);
+          tt = philox_uniform(a.seed, gp, a.rng_offset);
+          if (g == 0 && pidx[tl] < a.n_points) a.t[p] = tt;
+        }
+        const float* qa = a.traj + (b * a.n_way + j) * a.dim;  // traj[:-1]
+        const float* qb = qa + a.dim;                           // traj[1:]
+        if (a.dim == 3) {
+          // constrained:79-81  p = traj[1:] + t * wrap-theta(traj[:-1] - traj[1:])
+          float dx = qa[0] - qb[0], dy = qa[1] - qb[1], dth = wrap_angle(qa[2] - qb[2]);
+          x = qb[0] + tt * dx; y = qb[1] + tt * dy; ang = qb[2] + tt * dth;
+        } else {
+          // nerf:117  p = traj[1:] * (1 - t) + traj[:-1] * t
+          float omt = 1.0f - tt;
+          x = qb[0] * omt + qa[0] * tt; y = qb[1] * omt + qa[1] * tt;
+        }
+      }
+      ux[tl] = (x - geo.mean) / geo.sigma;  // onf_model.py:38
+      uy[tl] = (y - geo.mean) / geo.sigma;
+      th[tl] = ang;
+    }
+
+    // ---------------------------------------------------------------- L1: a1 = W1 in + b1, features just-in-time
+    f32x4 acc1[NT][HT];
+    float skip[NT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L::B1 + (mt < 6 ? 16 * mt + colQ : 96 + 4 * g));
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = bias;
+    }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) skip[tl] = 0.f;
+
+    int rowoff1[HT];  // A-operand row offsets of L1 (h1 layout Q)
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) rowoff1[mt] = (mt < 6 ? 16 * mt + rowposQ : 96 + gi) * S1;
+
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int fbase = base_p(kt) + colP;
+      const bool ang_tile = kt >= first_angle_kt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = fbase + r;
+        const f32x4 e0 = FT[2 * f];
+        const int flags = __float_as_int(lds[L::FT + 8 * f + 4]);
+        const float w3b = lds[L::W3B + f];
+        float fv[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+          float arg = ang_tile ? feature_arg<true>(e0, flags, ux[tl], uy[tl], th[tl])
+                               : feature_arg<false>(e0, flags, ux[tl], uy[tl], th[tl]);
+          fv[tl] = sin_quadrant(arg, flags & 1);
+          skip[tl] = fmaf(w3b, fv[tl], skip[tl]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          const float wa = W1[rowoff1[mt] + f];
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = mfma4(wa, fv[tl], acc1[tl][mt]);
+        }
+      }
+    }
+
+    // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
+    f32x4 acc2[NT][HT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L::B2 + (mt < 6 ? base_p(mt) + colP : 96 + 4 * g));
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = bias;
+    }
+    {
+      int rowoff2[HT];  // rows in h2 layout P
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) rowoff2[mt] = (mt < 6 ? base_p(mt) + rowposP : 96 + gi) * S2;
+      // 25 k-steps ks -> (t, r) = (ks >> 2, ks & 3); weights of step ks+1 are fetched while step ks multiplies
+      float wa[2][HT];
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) wa[0][mt] = W2[rowoff2[mt] + colQ];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int t = ks >> 2, r = ks & 3;
+        if (ks + 1 < KSTEPS) {
+          const int tn = (ks + 1) >> 2, rn = (ks + 1) & 3;
+          const int col = tn < 6 ? 16 * tn + rn + colQ : 96 + g;  // k index in h1 layout Q
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) wa[(ks + 1) & 1][mt] = W2[rowoff2[mt] + col];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs
+        float hb[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) hb[tl] = fmaxf(acc1[tl][t][r], 0.0f);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma4(wa[ks & 1][mt], hb[tl], acc2[tl][mt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---------------------------------------------------------------- logit and dh2 = W3a * [a2 > 0]
+    float logit[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) logit[tl] = skip[tl];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      const f32x4 w3a = *reinterpret_cast<const f32x4*>(lds + L::W3A + (mt < 6 ? base_p(mt) + colP : 96 + 4 * g));
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a2 = acc2[tl][mt][r];
+          logit[tl] = fmaf(w3a[r], fmaxf(a2, 0.0f), logit[tl]);
+          acc2[tl][mt][r] = a2 > 0.0f ? w3a[r] : 0.0f;  // becomes dh2
+        }
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      logit[tl] += __shfl_xor(logit[tl], 16);
+      logit[tl] += __shfl_xor(logit[tl], 32);
+      logit[tl] += b3;
+    }
+
+    // ---------------------------------------------------------------- L2T: dh1 = (W2^T dh2) * [a1 > 0]
+    {
+      f32x4 accd[NT][HT];
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int coloff[HT];  // output rows = h1 layout Q -> column of W2
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) coloff[mt] = mt < 6 ? 16 * mt + rowposQ : 96 + gi;
+      float wa[2][HT];
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) wa[0][mt] = W2[colP * S2 + coloff[mt]];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int t = ks >> 2, r = ks & 3;
+        if (ks + 1 < KSTEPS) {
+          const int tn = (ks + 1) >> 2, rn = (ks + 1) & 3;
+          const int row = (tn < 6 ? base_p(tn) + rn + colP : 96 + g) * S2;  // k index in h2 layout P
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) wa[(ks + 1) & 1][mt] = W2[row + coloff[mt]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma4(wa[ks & 1][mt], acc2[tl][t][r], accd[tl][mt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc1[tl][mt][r] = acc1[tl][mt][r] > 0.0f ? accd[tl][mt][r] : 0.0f;  // dh1
+    }
+
+    // ---------------------------------------------------------------- L1T: din = W1^T dh1 + W3b, then chain through the
+    // encodings: d/dx = sum_k din_k * d(feature_k)/dx  (feature derivative = next quadrant of the same argument)
+    float gx[NT], gy[NT], gt[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) gx[tl] = gy[tl] = gt[tl] = 0.f;
+    const int rowkQ = colQ * S1;  // k-step ks reads W1 row 16*t + r + colQ (h1 layout Q), (6,0) -> row 96 + g
+
+#pragma unroll 1
+    for (int mt = 0; mt < NKT; ++mt) {
+      const int fbase = base_p(mt) + colP;   // features of D rows (g, 0..3)
+      const int colA = base_p(mt) + rowposP; // A-operand column of W1 (output row i in layout P)
+      const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
+      f32x4 acc[NT];
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
+      // weights of this output tile: 25 values, fetched in groups of GRP k-steps one group ahead
+      constexpr int GRP = 5;
+      float wa[2][GRP];
+#pragma unroll
+      for (int k = 0; k < GRP; ++k) wa[0][k] = W1[rowkQ + (16 * (k >> 2) + (k & 3)) * S1 + colA];
+#pragma unroll
+      for (int grp = 0; grp < KSTEPS / GRP; ++grp) {
+        if (grp + 1 < KSTEPS / GRP) {
+#pragma unroll
+          for (int k = 0; k < GRP; ++k) {
+            const int ks = (grp + 1) * GRP + k, tn = ks >> 2, rn = ks & 3;
+            wa[(grp + 1) & 1][k] = tn < 6 ? W1[rowkQ + (16 * tn + rn) * S1 + colA] : W1[(96 + g) * S1 + colA];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+          const int ks = grp * GRP + k, t = ks >> 2, r = ks & 3;
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma4(wa[grp & 1][k], acc1[tl][t][r], acc[tl]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bool ang_tile = mt >= first_angle_kt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = fbase + r;
+        const f32x4 e0 = FT[2 * f];
+        const int flags = __float_as_int(lds[L::FT + 8 * f + 4]);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+          float arg = ang_tile ? feature_arg<true>(e0, flags, ux[tl], uy[tl], th[tl])
+                               : feature_arg<false>(e0, flags, ux[tl], uy[tl], th[tl]);
+          const float de = acc[tl][r] * sin_quadrant(arg, (flags & 1) + 1);
+          gx[tl] = fmaf(de, e0.x, gx[tl]);
+          gy[tl] = fmaf(de, e0.y, gy[tl]);
+          gt[tl] = fmaf(de, e0.w, gt[tl]);
+        }
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      gx[tl] += __shfl_xor(gx[tl], 16); gx[tl] += __shfl_xor(gx[tl], 32);
+      gy[tl] += __shfl_xor(gy[tl], 16); gy[tl] += __shfl_xor(gy[tl], 32);
+      gt[tl] += __shfl_xor(gt[tl], 16); gt[tl] += __shfl_xor(gt[tl], 32);
+      if (g == 0 && pidx[tl] < a.n_points) {
+        f32x4 o = {logit[tl], gx[tl] / geo.sigma, gy[tl] / geo.sigma, gt[tl]};
+        *reinterpret_cast<f32x4*>(a.out4 + pidx[tl] * 4) = o;
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+static int g_num_cus = 0;
+
+static int query_cus() {
+  if (g_num_cus > 0) return g_num_cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  return g_num_cus;
+}
+
+template <int NKT, int NT>
+static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
+  using L = Lds<NKT>;
+  static bool attr_set = false;
+  auto kern = onf_fwd_bwd_kernel<NKT, NT>;
+  if (!attr_set) {
+    NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)L::BYTES));
+    attr_set = true;
+  }
+  constexpr int CH = WAVES * 16 * NT;
+  long long n_chunks = (a.n_points + CH - 1) / CH;
+  long long grid = query_cus();
+  if (grid > n_chunks) grid = n_chunks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), L::BYTES, stream, a);
+  NFOPP_HIP(hipGetLastError());
+  return NFOPP_OK;
+}
+
+int launch_onf_kernel(const OnfKernelArgs& a, hipStream_t stream) {
+  if (a.n_points <= 0) return NFOPP_OK;
+  const int nkt = (a.geom.fin + 15) / 16;
+  // small jobs: one tile per wave so that more CUs take part; large jobs: two tiles per wave (half the LDS reads)
+  const bool small = a.n_points < (long long)query_cus() * WAVES * 16 * 2;
+  switch (nkt) {
+    case 14: return small ? launch_t<14, 1>(a, stream) : launch_t<14, 2>(a, stream);
+    case 13: return small ? launch_t<13, 1>(a, stream) : launch_t<13, 2>(a, stream);
+    case 8: return small ? launch_t<8, 1>(a, stream) : launch_t<8, 2>(a, stream);
+    case 7: return small ? launch_t<7, 1>(a, stream) : launch_t<7, 2>(a, stream);
+    default:
+      set_error("unsupported ONF feature dimension %d", a.geom.fin);
+      return NFOPP_ERR_ARG;
+  }
+}
+
+}  // namespace nfopp
+
+using namespace nfopp;
+
+extern "C" int nfopp_onf_eval_points(const nfopp_onf_config* cfg, const float* params_dev, const float* points_dev,
+                                     int64_t n_points, float* out4_dev, void* stream) {
+  OnfKernelArgs a = {};
+  NFOPP_REQUIRE(make_geom(cfg, &a.geom), "bad ONF configuration");
+  NFOPP_REQUIRE(params_dev && points_dev && out4_dev, "null device pointer");
+  NFOPP_REQUIRE(n_points >= 0, "negative point count");
+  a.params = params_dev;
+  a.points = points_dev;
+  a.n_points = n_points;
+  a.out4 = out4_dev;
+  return launch_onf_kernel(a, (hipStream_t)stream);
+}
+
+extern "C" int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const float* params_dev, const float* traj_dev,
+                                         int64_t batch, int32_t n_waypoints, int32_t dim, float* t_dev,
+                                         int32_t t_mode, uint64_t seed, uint64_t rng_offset,
+                                         int64_t traj_index_offset, float* out4_dev, void* stream) {
+  OnfKernelArgs a = {};
+  NFOPP_REQUIRE(make_geom(cfg, &a.geom), "bad ONF configuration");
+  NFOPP_REQUIRE(params_dev && traj_dev && t_dev && out4_dev, "null device pointer");
+  NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
+  NFOPP_REQUIRE(dim == a.geom.point_dim, "trajectory dim %d does not match the ONF point dim %d", dim,
+                a.geom.point_dim);
+  NFOPP_REQUIRE(t_mode == 0 || t_mode == 1, "t_mode must be 0 (read) or 1 (Philox)");
+  a.params = params_dev;
+  a.traj = traj_dev;
+  a.n_way = n_waypoints;
+  a.dim = dim;
+  a.t = t_dev;
+  a.t_mode = t_mode;
+  a.seed = seed;
+  a.rng_offset = rng_offset;
+  a.traj_index_offset = traj_index_offset;
+  a.n_points = batch * (int64_t)(n_waypoints - 1);
+  a.out4 = out4_dev;
+  return launch_onf_kernel(a, (hipStream_t)stream);
+}

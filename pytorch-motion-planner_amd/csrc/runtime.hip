@@ -1,0 +1,76 @@
+// Library-level plumbing: error strings, device query, the flat Adam update.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace nfopp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return e == hipErrorNoDevice ? NFOPP_ERR_NO_DEVICE : NFOPP_ERR_HIP;
+}
+
+// torch.optim.Adam single-tensor path on a flat buffer (ONF weights: nfop/nerf_opt_planner.py:90)
+__global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, long long n, float beta2, float omb1,
+                                 float omb2, float eps, float step_size, float bc2_sqrt) {
+  for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+    const float gk = g[k];
+    float mk = m[k], vk = v[k];
+    mk = mk + omb1 * (gk - mk);
+    vk = vk * beta2 + (omb2 * gk) * gk;
+    const float denom = sqrtf(vk) / bc2_sqrt + eps;
+    p[k] = p[k] - step_size * (mk / denom);
+    m[k] = mk;
+    v[k] = vk;
+  }
+}
+
+}  // namespace nfopp
+
+using namespace nfopp;
+
+extern "C" int nfopp_abi_version(void) { return NFOPP_ABI_VERSION; }
+
+extern "C" const char* nfopp_last_error(void) { return g_err; }
+
+extern "C" int nfopp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int64_t nfopp_onf_param_count(const nfopp_onf_config* cfg) {
+  OnfGeom g;
+  if (!make_geom(cfg, &g)) {
+    set_error("bad ONF configuration");
+    return NFOPP_ERR_ARG;
+  }
+  return g.n_params;
+}
+
+extern "C" int nfopp_adam_step(float* param_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n,
+                               float beta2, float omb1, float omb2, float eps, float step_size, float bc2_sqrt,
+                               void* stream) {
+  NFOPP_REQUIRE(param_dev && grad_dev && m_dev && v_dev, "null device pointer");
+  NFOPP_REQUIRE(n >= 0, "negative length");
+  if (n == 0) return NFOPP_OK;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param_dev, grad_dev,
+                     m_dev, v_dev, (long long)n, beta2, omb1, omb2, eps, step_size, bc2_sqrt);
+  NFOPP_HIP(hipGetLastError());
+  return NFOPP_OK;
+}

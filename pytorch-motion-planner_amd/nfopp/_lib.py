@@ -1,0 +1,107 @@
+"""ctypes binding of libnfopp_hip.so (C ABI: include/nfopp_hip.h).
+
+The HIP library is the ONLY compute path of this package.  If it is missing, or no MI355X is visible when a
+kernel is requested, calls raise `NfoppError` -- there is no CPU fallback by design.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnfopp_hip.so")
+ABI_VERSION = 1
+NUM_TERMS = 8
+TERM_NAMES = ("total", "distance", "softplus_sum", "lambda_dot_c", "c_squared", "boundary", "cm_tanh", "direction")
+
+
+class NfoppError(RuntimeError):
+    pass
+
+
+class OnfConfigC(ctypes.Structure):
+    _fields_ = [("mean", ctypes.c_float), ("sigma", ctypes.c_float), ("use_cos", ctypes.c_int32),
+                ("has_bias", ctypes.c_int32), ("angle_dim", ctypes.c_int32)]
+
+
+class TrajHyperC(ctypes.Structure):
+    _fields_ = [("collision_weight", ctypes.c_float), ("angle_weight", ctypes.c_float),
+                ("constraint_deltas_weight", ctypes.c_float), ("multipliers_lr", ctypes.c_float),
+                ("collision_multipliers_lr", ctypes.c_float), ("boundary_weight", ctypes.c_float),
+                ("collision_beta", ctypes.c_float), ("direction_delta_weight", ctypes.c_float),
+                ("bounds", ctypes.c_float * 4),
+                ("adam_beta2", ctypes.c_float), ("adam_omb1", ctypes.c_float), ("adam_omb2", ctypes.c_float),
+                ("adam_eps", ctypes.c_float), ("adam_step_size", ctypes.c_float), ("adam_bc2_sqrt", ctypes.c_float)]
+
+
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    "nfopp_abi_version": (ctypes.c_int, []),
+    "nfopp_last_error": (ctypes.c_char_p, []),
+    "nfopp_device_count": (ctypes.c_int, []),
+    "nfopp_onf_param_count": (ctypes.c_int64, [ctypes.POINTER(OnfConfigC)]),
+    "nfopp_onf_eval_points": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, ctypes.c_int64, _P, _P]),
+    "nfopp_traj_collision_eval": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, ctypes.c_int64, ctypes.c_int32,
+                                                 ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
+                                                 ctypes.c_int64, _P, _P]),
+    "nfopp_traj_update": (ctypes.c_int, [ctypes.POINTER(TrajHyperC), ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, _P, _P]),
+    "nfopp_reparametrize": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "nfopp_onf_train_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(OnfConfigC), ctypes.c_int64]),
+    "nfopp_onf_train_grad": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, _P, ctypes.c_int64, ctypes.c_float,
+                                            _P, _P, ctypes.c_size_t, _P]),
+    "nfopp_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (idempotent).  Loading needs no GPU; launching kernels does."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NfoppError("libnfopp_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "or `make -C pytorch-motion-planner_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nfopp_abi_version() != ABI_VERSION:
+        raise NfoppError("libnfopp_hip.so ABI %d != binding ABI %d" % (lib.nfopp_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise NfoppError("nfopp call failed (%d): %s" % (status, load().nfopp_last_error().decode(errors="replace")))
+
+
+def require_gpu():
+    lib = load()
+    if not torch.cuda.is_available() or lib.nfopp_device_count() < 1:
+        raise NfoppError("no HIP device visible: the NFOPP hot path runs on MI355X only (no CPU fallback)")
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise NfoppError("expected a contiguous %s HIP tensor, got %s" % (dtype, _describe(t)))
+    return t.data_ptr()
+
+
+def _describe(t):
+    if isinstance(t, torch.Tensor):
+        return "tensor(device=%s, dtype=%s, contiguous=%s, shape=%s)" % (t.device, t.dtype, t.is_contiguous(), tuple(t.shape))
+    return repr(type(t))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
