@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native NFOPP inner loop.
+
+Metric (BASELINE.json): waypoint-evals/sec = trajectories x waypoints x planner steps / wall seconds.
+Workload at N GPUs (BASELINE configs[2] per GPU, i.e. configs[3] at 8 GPUs): 4096 trajectories x 256 waypoints per
+GPU, random-obstacle map (300 discs on 100 m x 100 m), SE(2) constrained planner with the bench-mr hyper-parameters
+(reference scripts/run_bench_mr.py:45-63), ONF F=220 pre-fitted on the map and then FROZEN.  One "step" is one
+planner `.step()` for every trajectory: fused collision sampling + ONF fwd/bwd (MFMA kernel), loss terms + H^-1 +
+Adam + multiplier ascent (stencil kernel), and the arc-length reparametrisation every 10th step.  Inputs are
+resident in HBM before the timed region; the per-step interpolation draws come from the in-kernel Philox stream.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Trajectories shard contiguously across ranks (weak scaling, 4096 per GPU); the frozen-ONF step has no data-path
+collective.  Rank 0 prints ONE JSON line.  `roofline` = fused ONF kernel, algorithmic fp32 FLOPs (131 400 per
+collision sample) over its HIP-event duration vs the 157.3 TFLOP/s fp32 MFMA peak.  `cpu_baseline` =
+the oracle (oracle/nfopp_oracle.py, a numpy port with analytic gradients) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-motion-planner_amd"))
+sys.path.insert(0, ROOT)
+
+import nfopp  # noqa: E402
+
+FLOP_PER_SAMPLE = 131400.0      # 65 700 FMA per collision sample (fwd 32 740 + input-bwd 32 960)
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+B_PER_GPU, N_WAYPOINTS = 4096, 256
+BOUNDS = (0.0, 100.0, 0.0, 100.0)
+
+
+def make_environment():
+    rng = np.random.default_rng(1234)
+    return rng.uniform(5, 95, (300, 2)), 1.5
+
+
+def in_collision(xy, obstacles, radius):
+    d2 = ((xy[:, None, :] - obstacles[None]) ** 2).sum(-1)
+    out = (d2 < radius * radius).any(1)
+    out |= (xy[:, 0] < BOUNDS[0]) | (xy[:, 0] > BOUNDS[1]) | (xy[:, 1] < BOUNDS[2]) | (xy[:, 1] > BOUNDS[3])
+    return out
+
+
+def free_poses(rng, n, obstacles, radius):
+    out = np.zeros((0, 3))
+    while len(out) < n:
+        c = np.concatenate([rng.uniform(2, 98, (2 * n, 2)), rng.uniform(-np.pi, np.pi, (2 * n, 1))], 1)
+        out = np.concatenate([out, c[~in_collision(c[:, :2], obstacles, radius + 0.5)]])
+    return out[:n].astype(np.float32)
+
+
+def make_onf(device, obstacles, radius, fit_iters, fit_points):
+    """ONF of scripts/run_bench_mr.py:28-36 (sigma=10), fitted to the map with the HIP training kernel, then frozen."""
+    torch.random.manual_seed(100)
+    onf = nfopp.ONF(0, 10, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to(device)
+    fitter = nfopp.OnfFitter(onf, lr=2e-2, betas=(0.9, 0.9))
+    rng = np.random.default_rng(77)
+    for _ in range(fit_iters):
+        x = np.concatenate([rng.uniform(0, 100, (fit_points, 2)), rng.uniform(0, 2 * np.pi, (fit_points, 1))], 1)
+        y = in_collision(x[:, :2], obstacles, radius).astype(np.float32)
+        fitter.step(torch.tensor(x.astype(np.float32), device=device), torch.tensor(y, device=device), global_count=fit_points)
+    return onf, float(fitter.last_loss) if fit_iters else float("nan")
+
+
+def bench_hyper():
+    # reference scripts/run_bench_mr.py:37-63
+    return nfopp.TrajectoryHyper(collision_weight=100, angle_weight=5, constraint_deltas_weight=100, multipliers_lr=0.1,
+                                 collision_multipliers_lr=1e-3, boundary_weight=1, collision_beta=10,
+                                 direction_delta_weight=100, lr=5e-2, betas=(0.9, 0.9), eps=1e-8, bounds=BOUNDS)
+
+
+def cpu_baseline(onf_flat, starts, goals, sample_b, steps):
+    """Oracle (numpy port of the reference's algorithm) on the first `sample_b` trajectories of the workload."""
+    from oracle import nfopp_oracle as orc
+    try:
+        import threadpoolctl
+        threads = max([i["num_threads"] for i in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = 1
+    cfg = orc.OnfConfig(0, 10, True, True, True)
+    hp = orc.Hyper(100, 5, 100, 0.1, 1e-3, 1, 10, 100, 5e-2, 0.9, 0.9, 1e-8, BOUNDS)
+    n = N_WAYPOINTS
+    s = dict(traj=nfopp.straight_line_init(starts[:sample_b], goals[:sample_b], n), start=starts[:sample_b],
+             goal=goals[:sample_b], lam=np.zeros((sample_b, n + 1), np.float32), cm=np.zeros((sample_b, n), np.float32),
+             adam_m=np.zeros((sample_b, n, 3), np.float32), adam_v=np.zeros((sample_b, n, 3), np.float32),
+             adam_step=0, step_count=0)
+    hinv = orc.calculate_inv_hessian(n, 0.5)
+    rng = np.random.default_rng(5)
+    draw = lambda: rng.uniform(0, 1, (sample_b, n - 1)).astype(np.float32)  # noqa: E731
+    orc.planner_step(s, draw(), onf_flat, cfg, hp, hinv)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.planner_step(s, draw(), onf_flat, cfg, hp, hinv)
+    dt = time.perf_counter() - t0
+    return {"value": sample_b * n * steps / dt, "unit": "waypoint-evals/s", "cores": int(threads), "kind": "port",
+            "sample": "%d trajectories x %d waypoints x %d steps of the same workload (numpy oracle, %.1f s)"
+                      % (sample_b, n, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU)
+    ap.add_argument("--fit-iters", type=int, default=300)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    B, N = args.batch_per_gpu, N_WAYPOINTS
+    obstacles, radius = make_environment()
+    onf, fit_loss = make_onf(device, obstacles, radius, args.fit_iters, 4096)
+    rng = np.random.default_rng(4321)
+    starts = free_poses(rng, world * B, obstacles, radius)
+    goals = free_poses(rng, world * B, obstacles, radius)
+    lo, hi = nfopp.shard_range(world * B, rank, world)
+    planner = nfopp.BatchPlanner(onf, hi - lo, N, bench_hyper(), velocity_hessian_weight=0.5, device=device, seed=100,
+                                 traj_index_offset=lo)
+    planner.init(starts[lo:hi], goals[lo:hi], BOUNDS)
+    eng = planner.engine
+
+    def one_step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        eng.collision_eval()
+        if ev is not None:
+            ev[1].record()
+        eng.update(False)
+        if planner.step_count % planner.reparam_freq == 0:
+            eng.reparametrize()
+        planner.step_count += 1
+
+    for _ in range(args.warmup):
+        one_step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        k1_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        samples = (hi - lo) * (N - 1)
+        achieved = samples * FLOP_PER_SAMPLE / (k1_ms * 1e-3) / 1e12
+        paths = planner.get_paths()
+        finite = bool(np.isfinite(paths).all())
+        out = {
+            "metric": "waypoint-evals/sec", "value": world * B * N * args.steps / elapsed, "unit": "waypoint-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] per GPU: %d trajectories x %d waypoints, random-obstacle map "
+                                   "(300 discs r=1.5 on 100x100), SE(2) constrained planner, frozen pre-fitted ONF "
+                                   "(F=220, fit loss %.3f)" % (B, N, fit_loss),
+                       "trajectories_per_gpu": B, "waypoints": N, "global_batch": world * B,
+                       "parallelism": "trajectory shards, no data-path collective", "paths_finite": finite,
+                       "planner_steps_per_s": args.steps / elapsed},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "onf_fwd_bwd_kernel<14,2>", "kernel_ms": k1_ms,
+                         "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(onf.flat_parameters.cpu().numpy(), starts, goals,
+                                               min(args.cpu_sample, world * B), args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+"""Batched / sharded planning over B independent trajectories that share one ONF (the batch axis is new: the
+reference plans one trajectory per process, nfop/planner_factory.py:55,69).
+
+* `BatchPlanner`   -- B trajectories on one GPU: init / step / get_paths, frozen or continuously fitted ONF.
+* `shard_range`    -- contiguous split of a global batch over ranks; each rank passes its first global index as
+                      `traj_index_offset` so the in-kernel Philox stream (and hence every result) is independent of
+                      how the batch is sharded.  The frozen-ONF step needs NO collective.
+* `OnfFitter`      -- ONF fitting step for data-parallel continuous learning: local gradient kernel (normalised by
+                      the GLOBAL sample count), one all-reduce(SUM) of the flat [n_params + 2] buffer (RCCL over
+                      xGMI when the process group is "nccl"), then the identical Adam step on every rank, so the
+                      replicated weights stay bit-identical across ranks.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import TrajectoryEngine, TrajectoryHyper
+
+
+def shard_range(global_batch, rank, world_size):
+    """[lo, hi) of the trajectories owned by `rank` (contiguous, sizes differ by at most one)."""
+    base, rem = divmod(int(global_batch), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _linspace_rows(a, b, steps):
+    """Row-wise torch.linspace (fp32 CPU rounding: fp32 step, one fused multiply-add per element, two-sided)."""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    step = ((b - a) / np.float32(steps - 1)).astype(np.float32).astype(np.float64)
+    i = np.arange(steps)
+    lo = (a.astype(np.float64)[:, None] + step[:, None] * i[None]).astype(np.float32)
+    hi = (b.astype(np.float64)[:, None] - step[:, None] * (steps - 1 - i)[None]).astype(np.float32)
+    return np.where(i[None] < steps // 2, lo, hi)
+
+
+def straight_line_init(starts, goals, n_waypoints):
+    """Batched TrajectoryInitializer (nfop/trajectory_initializer.py:12-29): xy on the segment start->goal, theta
+    interpolated along the wrapped shortest rotation.  Host numpy, one-time per `init`."""
+    starts = np.asarray(starts, np.float32)
+    goals = np.asarray(goals, np.float32)
+    d = starts.shape[1]
+    out = np.zeros((starts.shape[0], n_waypoints, d), np.float32)
+    for k in range(2):
+        out[:, :, k] = _linspace_rows(starts[:, k], goals[:, k], n_waypoints + 2)[:, 1:-1]
+    if d == 3:
+        pi, two_pi = np.float32(np.pi), np.float32(2 * np.pi)
+        delta = (np.remainder((goals[:, 2] - starts[:, 2]) + pi, two_pi).astype(np.float32) - pi).astype(np.float32)
+        out[:, :, 2] = _linspace_rows(starts[:, 2], (delta + starts[:, 2]).astype(np.float32), n_waypoints + 2)[:, 1:-1]
+    return out
+
+
+class OnfFitter(object):
+    """One BCE/Adam step of the shared field on this rank's samples; gradients summed over `group` first."""
+
+    def __init__(self, onf, lr, betas, eps=1e-8, group=None, grad_fn=None):
+        self.onf, self.lr, self.betas, self.eps, self.group = onf, float(lr), tuple(betas), float(eps), group
+        flat = onf.flat_parameters
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.step_count = 0
+        self.grad = torch.zeros(onf.n_params + 2, dtype=torch.float32, device=flat.device)
+        self._ws = None
+        self._grad_fn = grad_fn or self._hip_grad
+        self._adam_fn = self._hip_adam if grad_fn is None else None
+        self.last_loss = None
+
+    def _hip_grad(self, samples, labels, inv_count):
+        lib = _lib.load()
+        cfg = self.onf.config_c()
+        p = samples.shape[0]
+        need = lib.nfopp_onf_train_workspace_bytes(cfg, p)
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=samples.device)
+        _lib.check(lib.nfopp_onf_train_grad(cfg, _lib.ptr(self.onf.flat_parameters), _lib.ptr(samples),
+                                            _lib.ptr(labels), p, inv_count, _lib.ptr(self.grad), _lib.ptr(self._ws),
+                                            self._ws.numel() * 4, _lib.stream_ptr()))
+
+    def _hip_adam(self, step_size, bc2_sqrt):
+        b1, b2 = self.betas
+        _lib.check(_lib.load().nfopp_adam_step(_lib.ptr(self.onf.flat_parameters), _lib.ptr(self.grad), _lib.ptr(self.m),
+                                               _lib.ptr(self.v), self.onf.n_params, b2, 1 - b1, 1 - b2, self.eps,
+                                               step_size, bc2_sqrt, _lib.stream_ptr()))
+
+    def global_count(self, local_count):
+        if self.group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return int(local_count)
+        c = torch.tensor([float(local_count)], dtype=torch.float64, device=self.grad.device)
+        torch.distributed.all_reduce(c, group=self.group)
+        return int(c.item())
+
+    def step(self, samples, labels, global_count=None, adam_fn=None):
+        """samples [P_local, point_dim], labels [P_local] on this rank's device.  Returns the global mean loss tensor."""
+        p = samples.shape[0]
+        total = self.global_count(p) if global_count is None else int(global_count)
+        self._grad_fn(samples, labels, 1.0 / total)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(self.grad, group=self.group)   # SUM; RCCL on the "nccl" backend
+        self.step_count += 1
+        b1, b2 = self.betas
+        step_size = self.lr / (1 - b1 ** self.step_count)
+        bc2_sqrt = (1 - b2 ** self.step_count) ** 0.5
+        (adam_fn or self._adam_fn)(step_size, bc2_sqrt)
+        self.last_loss = self.grad[self.onf.n_params]
+        return self.last_loss
+
+
+class BatchPlanner(object):
+    """B trajectories, one shared ONF, one GPU.  `step()` = ONE `_optimize_trajectory` per trajectory plus the
+    periodic reparametrisation, i.e. the frozen-ONF planner step of nfop/nerf_opt_planner.py:60-71 for the batch."""
+
+    def __init__(self, onf, batch, n_waypoints, hyper, velocity_hessian_weight=0.5, reparametrize_trajectory_freq=10,
+                 device="cuda", seed=0, traj_index_offset=0):
+        self.engine = TrajectoryEngine(onf, batch, n_waypoints, onf.point_dim, hyper, velocity_hessian_weight, device,
+                                       seed=seed, traj_index_offset=traj_index_offset)
+        self.onf = onf
+        self.reparam_freq = int(reparametrize_trajectory_freq)
+        self.step_count = 0
+
+    def init(self, starts, goals, boundaries, trajectories=None):
+        eng = self.engine
+        eng.set_endpoints(starts, goals)
+        h = eng.hyper
+        eng.hyper = TrajectoryHyper(h.collision_weight, h.angle_weight, h.constraint_deltas_weight, h.multipliers_lr,
+                                    h.collision_multipliers_lr, h.boundary_weight, h.collision_beta,
+                                    h.direction_delta_weight, h.lr, h.betas, h.eps, boundaries)
+        if trajectories is None:
+            trajectories = straight_line_init(starts, goals, eng.N)
+        eng.traj.copy_(torch.as_tensor(np.asarray(trajectories, np.float32)).reshape(eng.traj.shape))
+        for buf in (eng.lam, eng.cm, eng.adam_m, eng.adam_v):
+            if buf is not None:
+                buf.zero_()
+        eng.adam_step = 0
+        self.step_count = 0
+
+    def step(self, t=None, want_terms=False):
+        self.engine.optimize_trajectory(t, want_terms=want_terms)
+        if self.step_count % self.reparam_freq == 0:
+            self.engine.reparametrize()
+        self.step_count += 1
+
+    def get_paths(self):
+        return self.engine.full_trajectory().detach().cpu().numpy()
