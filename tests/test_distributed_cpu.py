@@ -1,0 +1,82 @@
+"""Multi-rank host logic on CPU (gloo, world_size 2): data-parallel ONF fitting = local gradient normalised by the
+GLOBAL sample count -> all-reduce(SUM) of the flat buffer -> identical Adam on every rank.  The HIP gradient kernel
+is replaced by the oracle through the fitter's test hook (no GPU here); the collective, the normalisation, the
+sharding and the replicated update are the code under test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "pytorch-motion-planner_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import nfopp
+    from oracle import nfopp_oracle as orc
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    z = np.load(os.path.join(GOLDEN, "g7_onf_train.npz"))
+    cfg = orc.OnfConfig.from_vector(z["cfg"])
+    onf = nfopp.ONF(cfg.mean, cfg.sigma, use_cos=True, bias=True, angle_encoding=True)
+    onf.load_flat(z["params_before"])
+    fitter = None
+
+    def grad_fn(samples, labels, inv_count):
+        # oracle gradient of sum_p loss_p * inv_count over the local samples (mean over P_local rescaled)
+        p_local = samples.shape[0]
+        loss, _, g = orc.onf_train_grads(onf.flat_parameters.numpy(), cfg, samples.numpy(), labels.numpy())
+        scale = p_local * inv_count
+        fitter.grad[:-2] = torch.tensor(g * np.float32(scale))
+        fitter.grad[-2] = float(loss) * scale
+        fitter.grad[-1] = p_local
+
+    def adam_fn(step_size, bc2_sqrt):
+        b1, b2 = fitter.betas
+        p, m, v = orc.adam_update(onf.flat_parameters.numpy(), fitter.grad[:-2].numpy(), fitter.m.numpy(), fitter.v.numpy(),
+                                  fitter.step_count, fitter.lr, b1, b2, fitter.eps)
+        onf.flat_parameters.copy_(torch.tensor(p))
+        fitter.m.copy_(torch.tensor(m))
+        fitter.v.copy_(torch.tensor(v))
+
+    fitter = nfopp.OnfFitter(onf, float(z["lr"]), (float(z["beta1"]), float(z["beta2"])), float(z["eps"]), grad_fn=grad_fn)
+    fitter.m.copy_(torch.tensor(z["adam_m_before"]))
+    fitter.v.copy_(torch.tensor(z["adam_v_before"]))
+    fitter.step_count = int(z["adam_step_before"])
+    total = z["x"].shape[0]
+    lo, hi = nfopp.shard_range(total, rank, world)       # uneven split: 209 samples over 2 ranks
+    x = torch.tensor(z["x"][lo:hi].astype(np.float32))
+    y = torch.tensor(z["labels"][lo:hi].astype(np.float32))
+    loss = fitter.step(x, y, adam_fn=adam_fn)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), params=onf.flat_parameters.numpy(), loss=float(loss),
+             count=float(fitter.grad[-1]), grad=fitter.grad[:-2].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_onf_fit_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = np.load(os.path.join(GOLDEN, "g7_onf_train.npz"))
+    r0, r1 = (np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(world))
+    assert np.array_equal(r0["params"], r1["params"])                       # replicas stay bit-identical
+    assert r0["count"] == z["x"].shape[0]
+    assert abs(float(r0["loss"]) - float(z["loss"])) < 2e-6                  # global mean loss
+    assert np.abs(r0["grad"] - z["grad"]).max() < 3e-6 * max(1.0, float(np.abs(z["grad"]).max()))
+    assert np.abs(r0["params"] - z["params_after"]).max() < 3e-6            # == the reference's full-batch step
