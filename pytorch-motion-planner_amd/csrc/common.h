@@ -98,6 +98,33 @@ __device__ __forceinline__ float sin_quadrant(float x, int q) {
   return __int_as_float(__float_as_int(res) ^ ((n & 2) << 30));
 }
 
+// Packed pair of sin(x + q*pi/2), q = 2*qh in {0, 1, 2, 3} (qh = "half turns of pi"): the transcendental of the
+// fused ONF kernel, written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.
+//   t = x/pi + qh;  j = rint(t) via the 1.5*2^23 magic add (its low mantissa bit is the parity of j);
+//   r = x - (j - qh)*pi  in [-pi/2, pi/2] (fma with a hi/lo split of pi);  result = (-1)^j * sin(r),
+// sin(r) = r + r^3 P(r^2), P minimax of degree 4 (max abs error 1.2e-7 for |x| < 400, checked in
+// tests/test_host_logic.py through an fp32 emulation against float64).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+__device__ __forceinline__ f32x2 sin_halfturns2(f32x2 x, f32x2 qh) {
+  const f32x2 t = fma2(x, splat2(0.318309886f), qh);
+  const f32x2 jm = t + splat2(12582912.0f);
+  const f32x2 jh = (jm - splat2(12582912.0f)) - qh;
+  f32x2 r = fma2(jh, splat2(-3.14159274101257324f), x);
+  r = fma2(jh, splat2(8.74227766e-08f), r);
+  r.x = __uint_as_float(__float_as_uint(r.x) ^ (__float_as_uint(jm.x) << 31));
+  r.y = __uint_as_float(__float_as_uint(r.y) ^ (__float_as_uint(jm.y) << 31));
+  const f32x2 s = r * r;
+  f32x2 p = fma2(splat2(-2.3909535684651928e-08f), s, splat2(2.7526637040864443e-06f));
+  p = fma2(p, s, splat2(-0.00019840894674416631f));
+  p = fma2(p, s, splat2(0.008333330973982811f));
+  p = fma2(p, s, splat2(-0.1666666716337204f));
+  return fma2(p, r * s, r);
+}
+
 // Philox4x32-10, first output word -> uniform [0,1) with 24 random bits (the same u32->float map torch uses).
 __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr_lo,
                                                 unsigned long long ctr_hi) {

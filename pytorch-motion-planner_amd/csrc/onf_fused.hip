@@ -16,6 +16,8 @@
 //    weight read of all four GEMMs bank-conflict-free from the SAME two LDS images;
 //  * input features sin/cos(W_e u + b_e), sin/cos((theta+b)f) are computed just-in-time as the L1 B operand and
 //    re-derived (shifted by a quadrant) in the L1T epilogue, so neither `in` nor `din` is ever stored.
+#include <type_traits>
+
 #include "common.h"
 
 namespace nfopp {
@@ -52,16 +54,22 @@ struct Lds {
   static constexpr int S1 = (NF > 128) ? 225 : 129;         // = 1 mod 32, > NF
   static constexpr int W1 = 0;
   static constexpr int W2 = W1 + H * S1;
-  static constexpr int FT = ((W2 + H * S2 + 3) / 4) * 4;  // feature table, 8 floats per input feature
-  static constexpr int B1 = FT + NF * 8;                  // 112 each, D-layout indexable (see fill)
+  static constexpr int FT = ((W2 + H * S2 + 3) / 4) * 4;  // feature table, FTS floats per input feature
+  static constexpr int FTS = 12;                          // (wx wx wy wy | b b fr fr | qh qh w3b w3b): packed-math pairs
+  static constexpr int B1 = FT + NF * FTS;                // 112 each, D-layout indexable (see fill)
   static constexpr int B2 = B1 + 16 * HT;
   static constexpr int W3A = B2 + 16 * HT;
   static constexpr int W3B = W3A + 16 * HT;               // NF skip weights
-  static constexpr int TOTAL = W3B + NF;
+  static constexpr int ISA = W3B + NF;                    // NF flags: 1.0 = angle feature
+  static constexpr int TOTAL = ISA + NF;
   static constexpr size_t BYTES = size_t(TOTAL) * 4;
 };
 
 __device__ __forceinline__ int base_p(int t) { return 32 * (t >> 1) + 8 * (t & 1); }
+
+// max(x, 0) as ONE instruction (fmaxf lowers to canonicalize + max).  Kept as a compiler-visible builtin: the result
+// feeds MFMA operands and hipcc inserts the VALU->MFMA wait states only for instructions it can see.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -83,25 +91,27 @@ __device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
     lds[L::W2 + idx] = col < H ? P[g.off_w2 + row * H + col] : 0.0f;
   }
   for (int f = tid; f < L::NF; f += THREADS) {
-    float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, w3b = 0.f;
-    int flags = 0;  // bit0: cosine feature, bit1: angle feature
+    // feature = sin(arg + qh*pi), qh = 0.5 for cosine features; every scalar is stored twice (a packed-math pair)
+    float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, w3b = 0.f, qh = 0.f, is_angle = 0.f;
     if (f < g.n_enc) {
       wx = P[g.off_we + 2 * f];
       wy = P[g.off_we + 2 * f + 1];
       b = g.off_be >= 0 ? P[g.off_be + f] : 0.0f;
-      flags = (g.n_enc > g.n_sin && f >= g.n_sin) ? 1 : 0;
+      qh = (g.n_enc > g.n_sin && f >= g.n_sin) ? 0.5f : 0.0f;
       w3b = P[g.off_w3 + H + f];
     } else if (f < g.fin) {
       int k = f - g.n_enc;
       b = P[g.off_ang_b + k];
       fr = P[g.off_ang_f + k];
-      flags = 2 | (k >= g.ang_dim ? 1 : 0);
+      qh = k >= g.ang_dim ? 0.5f : 0.0f;
+      is_angle = 1.0f;
       w3b = P[g.off_w3 + H + f];
     }
-    float* e = lds + L::FT + 8 * f;
-    e[0] = wx; e[1] = wy; e[2] = b; e[3] = fr;
-    e[4] = __int_as_float(flags); e[5] = 0.f; e[6] = 0.f; e[7] = 0.f;
+    float* e = lds + L::FT + L::FTS * f;
+    e[0] = e[1] = wx; e[2] = e[3] = wy; e[4] = e[5] = b; e[6] = e[7] = fr;
+    e[8] = e[9] = qh; e[10] = e[11] = w3b;
     lds[L::W3B + f] = w3b;
+    lds[L::ISA + f] = is_angle;
   }
   // hidden-indexed vectors: entries 0..95 natural; entries 96 + 4g + r hold feature 96+g for r == 0, else 0
   for (int k = tid; k < 16 * HT; k += THREADS) {
@@ -112,15 +122,18 @@ __device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
   }
 }
 
-// argument of input feature described by table entry e0 = (wx, wy, b, fr) for the point (ux, uy, th)
-template <bool MAY_BE_ANGLE>
-__device__ __forceinline__ float feature_arg(const f32x4 e0, int flags, float ux, float uy, float th) {
-  float arg = fmaf(e0.x, ux, fmaf(e0.y, uy, e0.z));  // encoding_layer: W_e u + b_e (onf_model.py:39)
+// Two input features at once (packed fp32): table entries e0 = (wx, wy, b, fr), (qh, is_angle) per slot,
+// points (ux, uy, th) per slot; DERIV adds half a turn of pi/2... i.e. evaluates d feature / d arg (L1T epilogue).
+template <bool MAY_BE_ANGLE, bool DERIV>
+__device__ __forceinline__ f32x2 features2(f32x2 wx, f32x2 wy, f32x2 b, f32x2 fr, f32x2 qh, f32x2 is_angle,
+                                           f32x2 ux, f32x2 uy, f32x2 th) {
+  f32x2 arg = fma2(wx, ux, fma2(wy, uy, b));  // encoding_layer: W_e u + b_e (onf_model.py:39)
   if (MAY_BE_ANGLE) {
-    float za = (th + e0.z) * e0.w;                   // (theta + b) * f (angle_encoder.py:16)
-    arg = (flags & 2) ? za : arg;
+    const f32x2 za = (th + b) * fr;            // (theta + b) * f (angle_encoder.py:16)
+    arg.x = is_angle.x != 0.0f ? za.x : arg.x;
+    arg.y = is_angle.y != 0.0f ? za.y : arg.y;
   }
-  return arg;
+  return sin_halfturns2(arg, DERIV ? qh + splat2(0.5f) : qh);
 }
 
 template <int NKT, int NT>
@@ -140,7 +153,6 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
 
   const float* W1 = lds + L::W1;
   const float* W2 = lds + L::W2;
-  const f32x4* FT = reinterpret_cast<const f32x4*>(lds + L::FT);
   constexpr int S1 = L::S1;
   constexpr int CH = WAVES * 16 * NT;
   const long long n_chunks = (a.n_points + CH - 1) / CH;
@@ -162,8 +174,16 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
         if (geo.point_dim == 3) ang = q[2];
       } else {
         const int nseg = a.n_way - 1;
-        long long b = p / nseg;
-        int j = (int)(p - b * nseg);
+        long long b;
+        int j;
+        if (a.n_points < 0x7fffffffLL) {  // wave-uniform: 32-bit division for every realistic batch
+          const unsigned b32 = (unsigned)p / (unsigned)nseg;
+          b = b32;
+          j = (int)((unsigned)p - b32 * (unsigned)nseg);
+        } else {
+          b = p / nseg;
+          j = (int)(p - b * nseg);
+        }
         float tt;
         if (a.t_mode == 0) {
           tt = a.t[p];
@@ -201,36 +221,68 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) skip[tl] = 0.f;
 
-    int rowoff1[HT];  // A-operand row offsets of L1 (h1 layout Q)
-#pragma unroll
-    for (int mt = 0; mt < HT; ++mt) rowoff1[mt] = (mt < 6 ? 16 * mt + rowposQ : 96 + gi) * S1;
+    // A-operand bases of L1 (rows in h1 layout Q): tiles 0..3, 4..5 and 6 get one lane base each so that every
+    // (mt, r) offset below is a compile-time immediate of the ds_read
+    const float* w1a = W1 + rowposQ * S1 + colP;
+    const float* w1b = w1a + 64 * S1;
+    const float* w1c = W1 + (96 + gi) * S1 + colP;
+    const float* ftl = lds + L::FT + L::FTS * colP;
+    const float* isl = lds + L::ISA + colP;
 
-#pragma unroll 1
-    for (int kt = 0; kt < NKT; ++kt) {
-      const int fbase = base_p(kt) + colP;
-      const bool ang_tile = kt >= first_angle_kt;
+    auto l1_tile = [&](auto ang_c, int kt) __attribute__((always_inline)) {
+      constexpr bool ANG = decltype(ang_c)::value;
+      constexpr bool ang_tile = ANG;
+      const int off = base_p(kt);
+      const float* fte = ftl + L::FTS * off;
+      const float* pa = w1a + off;
+      const float* pb = w1b + off;
+      const float* pc = w1c + off;
+      float fv[4][NT];
+      if (NT == 2) {  // pair = the two point tiles of this wave
+        const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
+        f32x2 sk = {skip[0], skip[NT - 1]};
+        f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};
+        if (ang_tile) isa4 = *reinterpret_cast<const f32x4*>(isl + off);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = fbase + r;
-        const f32x4 e0 = FT[2 * f];
-        const int flags = __float_as_int(lds[L::FT + 8 * f + 4]);
-        const float w3b = lds[L::W3B + f];
-        float fv[NT];
-#pragma unroll
-        for (int tl = 0; tl < NT; ++tl) {
-          float arg = ang_tile ? feature_arg<true>(e0, flags, ux[tl], uy[tl], th[tl])
-                               : feature_arg<false>(e0, flags, ux[tl], uy[tl], th[tl]);
-          fv[tl] = sin_quadrant(arg, flags & 1);
-          skip[tl] = fmaf(w3b, fv[tl], skip[tl]);
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r);      // wx wx wy wy
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 4);  // b b fr fr
+          const f32x4 e2 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 8);  // qh qh w3b w3b
+          const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
+          const f32x2 qh = {e2.x, e2.y}, w3 = {e2.z, e2.w};
+          const f32x2 v = features2<ANG, false>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
+          sk = fma2(w3, v, sk);
+          fv[r][0] = v.x; fv[r][NT - 1] = v.y;
         }
+        skip[0] = sk.x; skip[NT - 1] = sk.y;
+      } else {        // pair = two consecutive k-steps of the single tile
 #pragma unroll
-        for (int mt = 0; mt < HT; ++mt) {
-          const float wa = W1[rowoff1[mt] + f];
-#pragma unroll
-          for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = mfma4(wa, fv[tl], acc1[tl][mt]);
+        for (int r = 0; r < 4; r += 2) {
+          const float* ea = fte + L::FTS * r;
+          const float* eb = ea + L::FTS;
+          const f32x2 ux2 = splat2(ux[0]), uy2 = splat2(uy[0]), th2 = splat2(th[0]);
+          const f32x2 wx = {ea[0], eb[0]}, wy = {ea[2], eb[2]}, bb = {ea[4], eb[4]}, fr = {ea[6], eb[6]};
+          const f32x2 qh = {ea[8], eb[8]}, isa = {isl[off + r], isl[off + r + 1]};
+          const f32x2 v = features2<ANG, false>(wx, wy, bb, fr, qh, isa, ux2, uy2, th2);
+          skip[0] = fmaf(ea[10], v.x, skip[0]);
+          skip[0] = fmaf(eb[10], v.y, skip[0]);
+          fv[r][0] = v.x; fv[r + 1][0] = v.y;
         }
       }
-    }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          const float wa = mt < 4 ? pa[mt * 16 * S1 + r] : (mt < 6 ? pb[(mt - 4) * 16 * S1 + r] : pc[r]);
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = mfma4(wa, fv[r][tl], acc1[tl][mt]);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < first_angle_kt; ++kt) l1_tile(std::false_type{}, kt);
+#pragma unroll 1
+    for (int kt = first_angle_kt; kt < NKT; ++kt) l1_tile(std::true_type{}, kt);
 
     // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
     f32x4 acc2[NT][HT];
@@ -260,7 +312,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs
         float hb[NT];
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) hb[tl] = fmaxf(acc1[tl][t][r], 0.0f);
+        for (int tl = 0; tl < NT; ++tl) hb[tl] = relu1(acc1[tl][t][r]);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
@@ -281,7 +333,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a2 = acc2[tl][mt][r];
-          logit[tl] = fmaf(w3a[r], fmaxf(a2, 0.0f), logit[tl]);
+          logit[tl] = fmaf(w3a[r], relu1(a2), logit[tl]);
           acc2[tl][mt][r] = a2 > 0.0f ? w3a[r] : 0.0f;  // becomes dh2
         }
       }
@@ -337,8 +389,8 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
     for (int tl = 0; tl < NT; ++tl) gx[tl] = gy[tl] = gt[tl] = 0.f;
     const int rowkQ = colQ * S1;  // k-step ks reads W1 row 16*t + r + colQ (h1 layout Q), (6,0) -> row 96 + g
 
-#pragma unroll 1
-    for (int mt = 0; mt < NKT; ++mt) {
+    auto l1t_tile = [&](auto ang_c, int mt) __attribute__((always_inline)) {
+      constexpr bool ANG = decltype(ang_c)::value;
       const int fbase = base_p(mt) + colP;   // features of D rows (g, 0..3)
       const int colA = base_p(mt) + rowposP; // A-operand column of W1 (output row i in layout P)
       const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
@@ -368,23 +420,47 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      const bool ang_tile = mt >= first_angle_kt;
+      // chain through the encodings: d feature / d arg = sin(arg + (qh + 0.5) pi); rows (g, r) <-> slots (4 mt + r, g)
+      constexpr bool ang_tile = ANG;
+      const float* fte = lds + L::FT + L::FTS * fbase;
+      if (NT == 2) {
+        const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
+        f32x2 gx2 = {gx[0], gx[NT - 1]}, gy2 = {gy[0], gy[NT - 1]}, gt2 = {gt[0], gt[NT - 1]};
+        f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};
+        if (ang_tile) isa4 = *reinterpret_cast<const f32x4*>(lds + L::ISA + fbase);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = fbase + r;
-        const f32x4 e0 = FT[2 * f];
-        const int flags = __float_as_int(lds[L::FT + 8 * f + 4]);
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 4);
+          const f32x2 qh = *reinterpret_cast<const f32x2*>(fte + L::FTS * r + 8);
+          const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
+          const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
+          const f32x2 de = f32x2{acc[0][r], acc[NT - 1][r]} * cof;
+          gx2 = fma2(de, wx, gx2);
+          gy2 = fma2(de, wy, gy2);
+          gt2 = fma2(de, fr, gt2);
+        }
+        gx[0] = gx2.x; gx[NT - 1] = gx2.y; gy[0] = gy2.x; gy[NT - 1] = gy2.y; gt[0] = gt2.x; gt[NT - 1] = gt2.y;
+      } else {
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) {
-          float arg = ang_tile ? feature_arg<true>(e0, flags, ux[tl], uy[tl], th[tl])
-                               : feature_arg<false>(e0, flags, ux[tl], uy[tl], th[tl]);
-          const float de = acc[tl][r] * sin_quadrant(arg, (flags & 1) + 1);
-          gx[tl] = fmaf(de, e0.x, gx[tl]);
-          gy[tl] = fmaf(de, e0.y, gy[tl]);
-          gt[tl] = fmaf(de, e0.w, gt[tl]);
+        for (int r = 0; r < 4; r += 2) {
+          const float* ea = fte + L::FTS * r;
+          const float* eb = ea + L::FTS;
+          const f32x2 wx = {ea[0], eb[0]}, wy = {ea[2], eb[2]}, bb = {ea[4], eb[4]}, fr = {ea[6], eb[6]};
+          const f32x2 qh = {ea[8], eb[8]}, isa = {lds[L::ISA + fbase + r], lds[L::ISA + fbase + r + 1]};
+          const f32x2 ux2 = splat2(ux[0]), uy2 = splat2(uy[0]), th2 = splat2(th[0]);
+          const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, isa, ux2, uy2, th2);
+          const f32x2 de = f32x2{acc[0][r], acc[0][r + 1]} * cof;
+          gx[0] = fmaf(de.x, wx.x, gx[0]); gx[0] = fmaf(de.y, wx.y, gx[0]);
+          gy[0] = fmaf(de.x, wy.x, gy[0]); gy[0] = fmaf(de.y, wy.y, gy[0]);
+          gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]);
         }
       }
-    }
+    };
+#pragma unroll 1
+    for (int mt = 0; mt < first_angle_kt; ++mt) l1t_tile(std::false_type{}, mt);
+#pragma unroll 1
+    for (int mt = first_angle_kt; mt < NKT; ++mt) l1t_tile(std::true_type{}, mt);
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
       gx[tl] += __shfl_xor(gx[tl], 16); gx[tl] += __shfl_xor(gx[tl], 32);
