@@ -109,7 +109,51 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 
+// scalar form of the same routine (bitwise identical arithmetic per element)
+__device__ __forceinline__ float sin_halfturns1(float x, float qh) {
+  const float t = fmaf(x, 0.318309886f, qh);
+  const float jm = t + 12582912.0f;
+  const float jh = (jm - 12582912.0f) - qh;
+  float r = fmaf(jh, -3.14159274101257324f, x);
+  r = fmaf(jh, 8.74227766e-08f, r);
+  r = __uint_as_float(__float_as_uint(r) ^ (__float_as_uint(jm) << 31));
+  const float s = r * r;
+  float p = fmaf(-2.3909535684651928e-08f, s, 2.7526637040864443e-06f);
+  p = fmaf(p, s, -0.00019840894674416631f);
+  p = fmaf(p, s, 0.008333330973982811f);
+  p = fmaf(p, s, -0.1666666716337204f);
+  return fmaf(p, r * s, r);
+}
+
+// Hardware path: exact Cody-Waite reduction of x + qh*pi modulo 2 pi (fma with a hi/lo split of 2 pi), then
+// v_sin_f32 on the remainder expressed in revolutions (|f| <= 0.5).  Measured on gfx950 (tools/micro/
+// vsin_accuracy.hip): max |v_sin_f32(f) - sin(2 pi f)| = 1.25e-7; with the 3e-8-revolution rounding of f the
+// feature error stays <= 3e-7 absolute for any |x| < 1e5, at 5 VALU + 1 transcendental op instead of 15 VALU.
+__device__ __forceinline__ float sin_halfturns_hw(float x, float qq) {  // qq = offset in REVOLUTIONS (q/4)
+  const float jm = fmaf(x, 0.159154943f, 12582912.0f);  // 1.5*2^23 + x/2pi: the add rounds to the nearest turn
+  const float j = jm - 12582912.0f;                      // whole turns, exact
+  float r = fmaf(j, -6.28318548202514648f, x);           // x - j * 2pi  in [-pi, pi] (product exact in the fma)
+  r = fmaf(j, 1.74845553e-07f, r);
+  return __builtin_amdgcn_sinf(fmaf(r, 0.159154943f, qq));  // |revolutions| <= 0.75
+}
+
+#ifndef NFOPP_TRIG_MODE
+#define NFOPP_TRIG_MODE 2  /* 0 = scalar polynomial, 1 = packed polynomial, 2 = reduction + v_sin_f32 */
+#endif
+// sin_halfturns2(x, q * NFOPP_Q_UNIT) = sin(x + q*pi/2): the quadrant offset is pre-scaled to the unit the
+// selected routine works in (half turns of pi for the polynomials, revolutions for v_sin_f32)
+#if NFOPP_TRIG_MODE == 2
+#define NFOPP_Q_UNIT 0.25f
+#else
+#define NFOPP_Q_UNIT 0.5f
+#endif
+
 __device__ __forceinline__ f32x2 sin_halfturns2(f32x2 x, f32x2 qh) {
+#if NFOPP_TRIG_MODE == 0
+  return f32x2{sin_halfturns1(x.x, qh.x), sin_halfturns1(x.y, qh.y)};
+#elif NFOPP_TRIG_MODE == 2
+  return f32x2{sin_halfturns_hw(x.x, qh.x), sin_halfturns_hw(x.y, qh.y)};
+#endif
   const f32x2 t = fma2(x, splat2(0.318309886f), qh);
   const f32x2 jm = t + splat2(12582912.0f);
   const f32x2 jh = (jm - splat2(12582912.0f)) - qh;

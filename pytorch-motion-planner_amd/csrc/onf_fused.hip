@@ -67,9 +67,10 @@ struct Lds {
 
 __device__ __forceinline__ int base_p(int t) { return 32 * (t >> 1) + 8 * (t & 1); }
 
-// max(x, 0) as ONE instruction (fmaxf lowers to canonicalize + max).  Kept as a compiler-visible builtin: the result
-// feeds MFMA operands and hipcc inserts the VALU->MFMA wait states only for instructions it can see.
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// max(x, 0) as ONE integer instruction: for IEEE floats max_i32(bits, 0) clears every negative value (and -0)
+// and keeps every positive one.  (fmaxf lowers to canonicalize + max; an inline-asm v_max_f32 would hide the
+// VALU->MFMA operand hazard from hipcc.)
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -91,19 +92,20 @@ __device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
     lds[L::W2 + idx] = col < H ? P[g.off_w2 + row * H + col] : 0.0f;
   }
   for (int f = tid; f < L::NF; f += THREADS) {
-    // feature = sin(arg + qh*pi), qh = 0.5 for cosine features; every scalar is stored twice (a packed-math pair)
+    // feature = sin(arg + q*pi/2), q = 1 for cosine features, stored as qh = q * NFOPP_Q_UNIT; every scalar is
+    // stored twice (a packed-math pair)
     float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, w3b = 0.f, qh = 0.f, is_angle = 0.f;
     if (f < g.n_enc) {
       wx = P[g.off_we + 2 * f];
       wy = P[g.off_we + 2 * f + 1];
       b = g.off_be >= 0 ? P[g.off_be + f] : 0.0f;
-      qh = (g.n_enc > g.n_sin && f >= g.n_sin) ? 0.5f : 0.0f;
+      qh = (g.n_enc > g.n_sin && f >= g.n_sin) ? NFOPP_Q_UNIT : 0.0f;
       w3b = P[g.off_w3 + H + f];
     } else if (f < g.fin) {
       int k = f - g.n_enc;
       b = P[g.off_ang_b + k];
       fr = P[g.off_ang_f + k];
-      qh = k >= g.ang_dim ? 0.5f : 0.0f;
+      qh = k >= g.ang_dim ? NFOPP_Q_UNIT : 0.0f;
       is_angle = 1.0f;
       w3b = P[g.off_w3 + H + f];
     }
@@ -133,7 +135,7 @@ __device__ __forceinline__ f32x2 features2(f32x2 wx, f32x2 wy, f32x2 b, f32x2 fr
     arg.x = is_angle.x != 0.0f ? za.x : arg.x;
     arg.y = is_angle.y != 0.0f ? za.y : arg.y;
   }
-  return sin_halfturns2(arg, DERIV ? qh + splat2(0.5f) : qh);
+  return sin_halfturns2(arg, DERIV ? qh + splat2(NFOPP_Q_UNIT) : qh);
 }
 
 template <int NKT, int NT>
