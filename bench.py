@@ -107,6 +107,17 @@ def cpu_baseline(onf_flat, starts, goals, sample_b, steps):
                       % (sample_b, n, steps, dt)}
 
 
+def pmc_traffic(batch, n):
+    """HBM bytes per launch of the fused kernel from the committed PMC passes (profiles/r01_traffic.json, collected
+    with tools/gpu_pmc.sh on this workload); None when the workload differs or the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            d = json.load(f)
+        return float(d["bytes_per_launch"]) if (batch, n) == (B_PER_GPU, N_WAYPOINTS) else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +200,7 @@ def main():
                        "parallelism": "trajectory shards, no data-path collective", "paths_finite": finite,
                        "planner_steps_per_s": args.steps / elapsed},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(B, N),
                          "kernel": "onf_fwd_bwd_kernel<14,2>", "kernel_ms": k1_ms,
                          "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE},
         }
