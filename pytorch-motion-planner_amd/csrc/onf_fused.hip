@@ -532,8 +532,8 @@ extern "C" int nfopp_onf_eval_points(const nfopp_onf_config* cfg, const float* p
                                      int64_t n_points, float* out4_dev, void* stream) {
   OnfKernelArgs a = {};
   NFOPP_REQUIRE(make_geom(cfg, &a.geom), "bad ONF configuration");
-  NFOPP_REQUIRE(params_dev && points_dev && out4_dev, "null device pointer");
   NFOPP_REQUIRE(n_points >= 0, "negative point count");
+  NFOPP_REQUIRE(n_points == 0 || (params_dev && points_dev && out4_dev), "null device pointer");
   a.params = params_dev;
   a.points = points_dev;
   a.n_points = n_points;
@@ -547,8 +547,8 @@ extern "C" int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const floa
                                          int64_t traj_index_offset, float* out4_dev, void* stream) {
   OnfKernelArgs a = {};
   NFOPP_REQUIRE(make_geom(cfg, &a.geom), "bad ONF configuration");
-  NFOPP_REQUIRE(params_dev && traj_dev && t_dev && out4_dev, "null device pointer");
   NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
+  NFOPP_REQUIRE(batch == 0 || (params_dev && traj_dev && t_dev && out4_dev), "null device pointer");
   NFOPP_REQUIRE(dim == a.geom.point_dim, "trajectory dim %d does not match the ONF point dim %d", dim,
                 a.geom.point_dim);
   NFOPP_REQUIRE(t_mode == 0 || t_mode == 1, "t_mode must be 0 (read) or 1 (Philox)");

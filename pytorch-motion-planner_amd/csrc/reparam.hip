@@ -113,10 +113,10 @@ extern "C" int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t d
                                    const float* u_dev, void* stream) {
   NFOPP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
-  NFOPP_REQUIRE(traj_dev && start_dev && goal_dev && u_dev, "null device pointer");
-  NFOPP_REQUIRE(dim == 2 || (lam_dev && cm_dev), "SE(2) reparametrisation needs the multiplier arrays");
   NFOPP_REQUIRE(batch <= 0x7fffffffLL, "batch too large for one launch");
   if (batch == 0) return NFOPP_OK;
+  NFOPP_REQUIRE(traj_dev && start_dev && goal_dev && u_dev, "null device pointer");
+  NFOPP_REQUIRE(dim == 2 || (lam_dev && cm_dev), "SE(2) reparametrisation needs the multiplier arrays");
   ReparamArgs a;
   a.n = n_waypoints; a.dim = dim; a.traj = traj_dev; a.start = start_dev; a.goal = goal_dev;
   a.lam = lam_dev; a.cm = cm_dev; a.u = u_dev;

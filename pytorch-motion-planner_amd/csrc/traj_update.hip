@@ -286,12 +286,12 @@ extern "C" int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int3
   NFOPP_REQUIRE(hp, "null hyper-parameter block");
   NFOPP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
+  NFOPP_REQUIRE(half_width >= 0, "negative band half-width");
+  if (batch == 0) return NFOPP_OK;
   NFOPP_REQUIRE(traj_dev && start_dev && goal_dev && adam_m_dev && adam_v_dev && t_dev && onf_out4_dev &&
                     hinv_band_dev,
                 "null device pointer");
   NFOPP_REQUIRE(dim == 2 || (lam_dev && cm_dev), "SE(2) update needs the multiplier arrays");
-  NFOPP_REQUIRE(half_width >= 0, "negative band half-width");
-  if (batch == 0) return NFOPP_OK;
   TrajUpdateArgs a;
   a.hp = *hp;
   a.batch = batch; a.n = n_waypoints; a.dim = dim;

@@ -94,7 +94,7 @@ def ptr(t, dtype=torch.float32):
         return None
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise NfoppError("expected a contiguous %s HIP tensor, got %s" % (dtype, _describe(t)))
-    return t.data_ptr()
+    return t.data_ptr() or None   # empty tensors have no storage: pass NULL (the C side accepts it for size 0)
 
 
 def _describe(t):
