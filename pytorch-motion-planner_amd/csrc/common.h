@@ -69,9 +69,15 @@ inline bool make_geom(const nfopp_onf_config* c, OnfGeom* g) {
 #define NFOPP_TWO_PI_F 6.28318548202514648f  /* fp32(2 pi) */
 
 // nfop/torch_math.py:5-7: (a + pi) % (2 pi) - pi, remainder with the divisor's sign, all in fp32.
+// r = x - floor(x / 2pi) * 2pi through one fma: the true remainder is exactly representable, so the fma returns the
+// same correctly rounded value torch's fmod-then-adjust produces; the two fix-ups only fire when x / 2pi rounds
+// across an integer (remainder within 1 ulp of 0 or 2 pi).
 __device__ __forceinline__ float wrap_angle(float a) {
-  float r = fmodf(a + NFOPP_PI_F, NFOPP_TWO_PI_F);
+  const float x = a + NFOPP_PI_F;
+  const float k = floorf(x * 0.159154943f);
+  float r = fmaf(-k, NFOPP_TWO_PI_F, x);
   if (r < 0.0f) r += NFOPP_TWO_PI_F;
+  if (r >= NFOPP_TWO_PI_F) r -= NFOPP_TWO_PI_F;
   return r - NFOPP_PI_F;
 }
 

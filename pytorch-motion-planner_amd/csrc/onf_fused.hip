@@ -335,8 +335,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a2 = acc2[tl][mt][r];
-          logit[tl] = fmaf(w3a[r], relu1(a2), logit[tl]);
-          acc2[tl][mt][r] = a2 > 0.0f ? w3a[r] : 0.0f;  // becomes dh2
+          const float d2 = a2 > 0.0f ? w3a[r] : 0.0f;   // dh2 = W3a * [a2 > 0]
+          logit[tl] = fmaf(d2, a2, logit[tl]);          // = W3a * relu(a2)
+          acc2[tl][mt][r] = d2;
         }
       }
     }

@@ -75,7 +75,7 @@ __device__ __forceinline__ SegOut segment_terms(const nfopp_traj_hyper& hp, floa
   o.tx = -o.hx; o.ty = -o.hy; o.tth = -o.hth;
   // A5 non-holonomic (constrained:102-109)
   const float m = th0 + wrap_angle(th1 - th0) * 0.5f;
-  const float sm = sin_quadrant(m, 0), cm_ = sin_quadrant(m, 1);
+  const float sm = sin_halfturns_hw(m, 0.0f), cm_ = sin_halfturns_hw(m, 0.25f);
   const float c = dx * sm - dy * cm_;
   const float e = dx * cm_ + dy * sm;
   const float gg = lam_s + (2.0f * hp.constraint_deltas_weight) * c;
@@ -85,7 +85,7 @@ __device__ __forceinline__ SegOut segment_terms(const nfopp_traj_hyper& hp, floa
   o.hth += gg * e * 0.5f; o.tth += gg * e * 0.5f;
   // A6 direction / forward-only (constrained:111-118,93,98)
   const float mp = th0 + wrap_angle(th0 - th1) * 0.5f;
-  const float smp = sin_quadrant(mp, 0), cmp_ = sin_quadrant(mp, 1);
+  const float smp = sin_halfturns_hw(mp, 0.0f), cmp_ = sin_halfturns_hw(mp, 0.25f);
   const float d = -(cmp_ * dx + smp * dy);
   const float r = d > 0.0f ? d : 0.0f;
   o.l_dir = r * r;
