@@ -125,6 +125,12 @@ int nfopp_onf_train_grad(const nfopp_onf_config* cfg, const float* params_dev, c
                          const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Same, with an explicit implementation path: 0 = automatic (MFMA GEMM path from 2048 samples), 1 = per-sample
+ * workgroups + thread-per-parameter reductions, 2 = MFMA forward/backward + split-K weight-gradient GEMMs. */
+int nfopp_onf_train_grad_ex(const nfopp_onf_config* cfg, const float* params_dev, const float* samples_dev,
+                            const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
+                            void* workspace_dev, size_t workspace_bytes, int32_t path, void* stream);
+
 /* torch.optim.Adam single-tensor update on a flat buffer (used for the ONF weights after the gradient
  * all-reduce): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps). */
 int nfopp_adam_step(float* param_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, float beta2,

@@ -18,7 +18,7 @@
 //    re-derived (shifted by a quadrant) in the L1T epilogue, so neither `in` nor `din` is ever stored.
 #include <type_traits>
 
-#include "common.h"
+#include "onf_kernel.h"
 
 namespace nfopp {
 
@@ -31,21 +31,6 @@ constexpr int THREADS = 512;
 constexpr int WAVES = THREADS / 64;
 constexpr int KSTEPS = 25;  // hidden k-steps: ks -> tile ks>>2, register ks&3 (tile 6 only register 0)
 
-struct OnfKernelArgs {
-  OnfGeom geom;
-  const float* params;
-  // explicit-point mode
-  const float* points;
-  // trajectory mode (points == nullptr)
-  const float* traj;
-  int n_way, dim;
-  float* t;
-  int t_mode;
-  unsigned long long seed, rng_offset;
-  long long traj_index_offset;
-  long long n_points;
-  float* out4;
-};
 
 template <int NKT>
 struct Lds {
@@ -77,7 +62,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 
 // ---- stage the flat parameter buffer into LDS ---------------------------------------------------------------
-template <int NKT>
+template <int NKT, bool TRAIN>
 __device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
   using L = Lds<NKT>;
   const OnfGeom& g = a.geom;
@@ -108,6 +93,8 @@ __device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
       qh = k >= g.ang_dim ? NFOPP_Q_UNIT : 0.0f;
       is_angle = 1.0f;
       w3b = P[g.off_w3 + H + f];
+    } else if (TRAIN && f == a.aug_feature) {
+      qh = NFOPP_Q_UNIT;  // all weights zero: sin(0 + pi/2) = 1
     }
     float* e = lds + L::FT + L::FTS * f;
     e[0] = e[1] = wx; e[2] = e[3] = wy; e[4] = e[5] = b; e[6] = e[7] = fr;
@@ -138,11 +125,11 @@ __device__ __forceinline__ f32x2 features2(f32x2 wx, f32x2 wy, f32x2 b, f32x2 fr
   return sin_halfturns2(arg, DERIV ? qh + splat2(NFOPP_Q_UNIT) : qh);
 }
 
-template <int NKT, int NT>
+template <int NKT, int NT, bool TRAIN>
 __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernelArgs a) {
   using L = Lds<NKT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds<NKT>(lds, a);
+  fill_lds<NKT, TRAIN>(lds, a);
   __syncthreads();
 
   const OnfGeom& geo = a.geom;
@@ -159,6 +146,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
   constexpr int CH = WAVES * 16 * NT;
   const long long n_chunks = (a.n_points + CH - 1) / CH;
   const float b3 = a.params[geo.off_b3];
+  constexpr int WIN = 16 * NKT;   // row length of the input-side factor matrices (TRAIN)
+  constexpr int WH = 16 * HT;     // row length of the hidden-side factor matrices
+  float loss_acc = 0.f;
 
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // ---------------------------------------------------------------- sample / load the wave's points
@@ -209,6 +199,8 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
       ux[tl] = (x - geo.mean) / geo.sigma;  // onf_model.py:38
       uy[tl] = (y - geo.mean) / geo.sigma;
       th[tl] = ang;
+      if (TRAIN && g == 0 && pidx[tl] < a.n_points)
+        *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 4) = f32x4{ux[tl], uy[tl], 1.0f, ang};
     }
 
     // ---------------------------------------------------------------- L1: a1 = W1 in + b1, features just-in-time
@@ -271,6 +263,13 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
           fv[r][0] = v.x; fv[r + 1][0] = v.y;
         }
       }
+      if (TRAIN) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+          if (pidx[tl] < a.n_points)
+            *reinterpret_cast<f32x4*>(a.ws_in + pidx[tl] * WIN + 16 * kt + 4 * g) =
+                f32x4{fv[0][tl], fv[1][tl], fv[2][tl], fv[3][tl]};
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -285,6 +284,19 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
     for (int kt = 0; kt < first_angle_kt; ++kt) l1_tile(std::false_type{}, kt);
 #pragma unroll 1
     for (int kt = first_angle_kt; kt < NKT; ++kt) l1_tile(std::true_type{}, kt);
+
+    if (TRAIN) {  // h1 (layout Q slots), ones at slot (tile 6, g = 0, r = 1)
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl)
+        if (pidx[tl] < a.n_points) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            f32x4 v = {relu1(acc1[tl][t][0]), relu1(acc1[tl][t][1]), relu1(acc1[tl][t][2]), relu1(acc1[tl][t][3])};
+            if (t == 6) v = f32x4{v[0], g == 0 ? 1.0f : 0.0f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(a.ws_h1 + pidx[tl] * WH + 16 * t + 4 * g) = v;
+          }
+        }
+    }
 
     // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
     f32x4 acc2[NT][HT];
@@ -324,6 +336,18 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
     }
 
     // ---------------------------------------------------------------- logit and dh2 = W3a * [a2 > 0]
+    if (TRAIN) {
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl)
+        if (pidx[tl] < a.n_points) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            f32x4 v = {relu1(acc2[tl][t][0]), relu1(acc2[tl][t][1]), relu1(acc2[tl][t][2]), relu1(acc2[tl][t][3])};
+            if (t == 6) v = f32x4{v[0], 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(a.ws_h2 + pidx[tl] * WH + 16 * t + 4 * g) = v;
+          }
+        }
+    }
     float logit[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) logit[tl] = skip[tl];
@@ -341,11 +365,32 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
         }
       }
     }
+    float rho[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
       logit[tl] += __shfl_xor(logit[tl], 16);
       logit[tl] += __shfl_xor(logit[tl], 32);
       logit[tl] += b3;
+      rho[tl] = 1.0f;
+      if (TRAIN) {
+        // BCE-with-logits, mean over the job's samples (nerf:25,88): rho = (sigmoid(l) - y) / count
+        const bool valid = pidx[tl] < a.n_points;
+        const float y = valid ? a.labels[pidx[tl]] : 0.0f;
+        const float l = logit[tl];
+        const float lp = fmaxf(l, 0.0f) - l * y + log1pf(expf(-fabsf(l)));
+        rho[tl] = valid ? (1.0f / (1.0f + expf(-l)) - y) * a.inv_count : 0.0f;
+        if (valid && g == 0) loss_acc += lp * a.inv_count;
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) acc2[tl][mt] = acc2[tl][mt] * rho[tl];
+        if (valid) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            f32x4 v = acc2[tl][t];
+            if (t == 6) v = f32x4{v[0], g == 0 ? rho[tl] : 0.0f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(a.ws_dh2 + pidx[tl] * WH + 16 * t + 4 * g) = v;
+          }
+        }
+      }
     }
 
     // ---------------------------------------------------------------- L2T: dh1 = (W2^T dh2) * [a1 > 0]
@@ -383,6 +428,18 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
         for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc1[tl][mt][r] = acc1[tl][mt][r] > 0.0f ? accd[tl][mt][r] : 0.0f;  // dh1
+      if (TRAIN) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+          if (pidx[tl] < a.n_points) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+              f32x4 v = acc1[tl][t];
+              if (t == 6) v = f32x4{v[0], g == 0 ? rho[tl] : 0.0f, 0.f, 0.f};
+              *reinterpret_cast<f32x4*>(a.ws_dh1 + pidx[tl] * WH + 16 * t + 4 * g) = v;
+            }
+          }
+      }
     }
 
     // ---------------------------------------------------------------- L1T: din = W1^T dh1 + W3b, then chain through the
@@ -399,7 +456,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
       const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
       f32x4 acc[NT];
 #pragma unroll
-      for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
+      for (int tl = 0; tl < NT; ++tl) acc[tl] = TRAIN ? w3b * rho[tl] : w3b;
       // weights of this output tile: 25 values, fetched in groups of GRP k-steps one group ahead
       constexpr int GRP = 5;
       float wa[2][GRP];
@@ -439,6 +496,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
           const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
           const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
           const f32x2 de = f32x2{acc[0][r], acc[NT - 1][r]} * cof;
+          if (TRAIN) { acc[0][r] = de.x; acc[NT - 1][r] = de.y; }
           gx2 = fma2(de, wx, gx2);
           gy2 = fma2(de, wy, gy2);
           gt2 = fma2(de, fr, gt2);
@@ -454,10 +512,17 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
           const f32x2 ux2 = splat2(ux[0]), uy2 = splat2(uy[0]), th2 = splat2(th[0]);
           const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, isa, ux2, uy2, th2);
           const f32x2 de = f32x2{acc[0][r], acc[0][r + 1]} * cof;
+          if (TRAIN) { acc[0][r] = de.x; acc[0][r + 1] = de.y; }
           gx[0] = fmaf(de.x, wx.x, gx[0]); gx[0] = fmaf(de.y, wx.y, gx[0]);
           gy[0] = fmaf(de.x, wy.x, gy[0]); gy[0] = fmaf(de.y, wy.y, gy[0]);
           gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]);
         }
+      }
+      if (TRAIN) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+          if (pidx[tl] < a.n_points)
+            *reinterpret_cast<f32x4*>(a.ws_de + pidx[tl] * WIN + 16 * mt + 4 * g) = acc[tl];
       }
     };
 #pragma unroll 1
@@ -469,11 +534,16 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
       gx[tl] += __shfl_xor(gx[tl], 16); gx[tl] += __shfl_xor(gx[tl], 32);
       gy[tl] += __shfl_xor(gy[tl], 16); gy[tl] += __shfl_xor(gy[tl], 32);
       gt[tl] += __shfl_xor(gt[tl], 16); gt[tl] += __shfl_xor(gt[tl], 32);
-      if (g == 0 && pidx[tl] < a.n_points) {
+      if (a.out4 && g == 0 && pidx[tl] < a.n_points) {
         f32x4 o = {logit[tl], gx[tl] / geo.sigma, gy[tl] / geo.sigma, gt[tl]};
         *reinterpret_cast<f32x4*>(a.out4 + pidx[tl] * 4) = o;
       }
     }
+  }
+  if (TRAIN) {  // fixed-order loss partial: lanes of a wave (xor tree), then waves / workgroups in the final kernel
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o);
+    if (lane == 0) a.loss_partial[blockIdx.x * WAVES + wave] = loss_acc;
   }
 }
 
@@ -490,11 +560,11 @@ static int query_cus() {
   return g_num_cus;
 }
 
-template <int NKT, int NT>
-static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
+template <int NKT, int NT, bool TRAIN = false>
+static int launch_t(const OnfKernelArgs& a, hipStream_t stream, int* grid_out = nullptr) {
   using L = Lds<NKT>;
   static bool attr_set = false;
-  auto kern = onf_fwd_bwd_kernel<NKT, NT>;
+  auto kern = onf_fwd_bwd_kernel<NKT, NT, TRAIN>;
   if (!attr_set) {
     NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)L::BYTES));
@@ -504,6 +574,7 @@ static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
   long long n_chunks = (a.n_points + CH - 1) / CH;
   long long grid = query_cus();
   if (grid > n_chunks) grid = n_chunks;
+  if (grid_out) *grid_out = (int)grid;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), L::BYTES, stream, a);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;
@@ -517,13 +588,30 @@ int launch_onf_kernel(const OnfKernelArgs& a, hipStream_t stream) {
   switch (nkt) {
     case 14: return small ? launch_t<14, 1>(a, stream) : launch_t<14, 2>(a, stream);
     case 13: return small ? launch_t<13, 1>(a, stream) : launch_t<13, 2>(a, stream);
-    case 8: return small ? launch_t<8, 1>(a, stream) : launch_t<8, 2>(a, stream);
-    case 7: return small ? launch_t<7, 1>(a, stream) : launch_t<7, 2>(a, stream);
+    case 8: return launch_t<8, 1>(a, stream);   // 7-8 input tiles: NT = 2 spills (S1 = 129 images), keep one tile
+    case 7: return launch_t<7, 1>(a, stream);
     default:
       set_error("unsupported ONF feature dimension %d", a.geom.fin);
       return NFOPP_ERR_ARG;
   }
 }
+
+// training forward/backward pass (factor matrices for csrc/onf_wgrad.hip); one tile per wave: the factor stores
+// need the registers the second tile would take
+int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out) {
+  const int nkt = (a.geom.fin + 15) / 16;
+  switch (nkt) {
+    case 14: return launch_t<14, 1, true>(a, stream, grid_out);
+    case 13: return launch_t<13, 1, true>(a, stream, grid_out);
+    case 8: return launch_t<8, 1, true>(a, stream, grid_out);
+    case 7: return launch_t<7, 1, true>(a, stream, grid_out);
+    default:
+      set_error("unsupported ONF feature dimension %d", a.geom.fin);
+      return NFOPP_ERR_ARG;
+  }
+}
+
+int onf_train_grid_upper_bound() { return query_cus(); }
 
 }  // namespace nfopp
 

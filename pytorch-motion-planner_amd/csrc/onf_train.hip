@@ -12,7 +12,7 @@
 //   3. onf_train_final_kernel  : sums the chunk partials (and the per-sample losses) in chunk order
 // Version 1 is sized for the single-trajectory planner (P = N + 109 samples per step); the large-P path of
 // BASELINE config 5 reuses it with more chunks (an MFMA split-K version is future work).
-#include "common.h"
+#include "onf_kernel.h"
 
 namespace nfopp {
 
@@ -227,27 +227,54 @@ __global__ __launch_bounds__(256) void onf_train_final_kernel(const ReduceArgs a
 
 using namespace nfopp;
 
+static const long long MFMA_PATH_MIN_SAMPLES = 2048;  // below this the per-sample path is launch-bound anyway
+
+static int train_grad_per_sample(const OnfGeom& g, const float* params_dev, const float* samples_dev,
+                                 const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
+                                 void* workspace_dev, hipStream_t st);
+
 extern "C" size_t nfopp_onf_train_workspace_bytes(const nfopp_onf_config* cfg, int64_t n_samples) {
   OnfGeom g;
   if (!make_geom(cfg, &g) || n_samples < 0) return 0;
-  return (size_t)carve(g, n_samples).total * sizeof(float);
+  const size_t a = (size_t)carve(g, n_samples).total * sizeof(float);
+  const size_t b = wgrad_workspace_bytes(g, n_samples);
+  return a > b ? a : b;
+}
+
+extern "C" int nfopp_onf_train_grad_ex(const nfopp_onf_config* cfg, const float* params_dev, const float* samples_dev,
+                                       const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
+                                       void* workspace_dev, size_t workspace_bytes, int32_t path, void* stream) {
+  OnfGeom g;
+  NFOPP_REQUIRE(make_geom(cfg, &g), "bad ONF configuration");
+  NFOPP_REQUIRE(g.fin <= 256, "feature dimension %d too large", g.fin);
+  NFOPP_REQUIRE(params_dev && samples_dev && labels_dev && grad_dev && workspace_dev, "null device pointer");
+  NFOPP_REQUIRE(n_samples > 0 && n_samples <= 0x7fffffffLL, "sample count out of range");
+  NFOPP_REQUIRE(path >= 0 && path <= 2, "path must be 0 (auto), 1 (per-sample) or 2 (MFMA)");
+  NFOPP_REQUIRE(workspace_bytes >= nfopp_onf_train_workspace_bytes(cfg, n_samples),
+                "workspace too small: %zu < %zu bytes", workspace_bytes, nfopp_onf_train_workspace_bytes(cfg, n_samples));
+  const bool mfma = path == 2 || (path == 0 && n_samples >= MFMA_PATH_MIN_SAMPLES);
+  if (mfma)
+    return onf_train_grad_mfma(g, params_dev, samples_dev, labels_dev, n_samples, inv_count, grad_dev,
+                               (float*)workspace_dev, (hipStream_t)stream);
+  return train_grad_per_sample(g, params_dev, samples_dev, labels_dev, n_samples, inv_count, grad_dev, workspace_dev,
+                               (hipStream_t)stream);
 }
 
 extern "C" int nfopp_onf_train_grad(const nfopp_onf_config* cfg, const float* params_dev, const float* samples_dev,
                                     const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
                                     void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return nfopp_onf_train_grad_ex(cfg, params_dev, samples_dev, labels_dev, n_samples, inv_count, grad_dev, workspace_dev,
+                                 workspace_bytes, 0, stream);
+}
+
+static int train_grad_per_sample(const OnfGeom& g, const float* params_dev, const float* samples_dev,
+                                 const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
+                                 void* workspace_dev, hipStream_t st) {
   TrainArgs a = {};
-  NFOPP_REQUIRE(make_geom(cfg, &a.geom), "bad ONF configuration");
-  NFOPP_REQUIRE(a.geom.fin <= 256, "feature dimension %d too large", a.geom.fin);
-  NFOPP_REQUIRE(params_dev && samples_dev && labels_dev && grad_dev && workspace_dev, "null device pointer");
-  NFOPP_REQUIRE(n_samples > 0 && n_samples <= 0x7fffffffLL, "sample count out of range");
-  const OnfGeom& g = a.geom;
+  a.geom = g;
   a.w = carve(g, n_samples);
-  NFOPP_REQUIRE(workspace_bytes >= (size_t)a.w.total * sizeof(float), "workspace too small: %zu < %zu bytes",
-                workspace_bytes, (size_t)a.w.total * sizeof(float));
   a.params = params_dev; a.samples = samples_dev; a.labels = labels_dev; a.P = n_samples;
   a.inv_count = inv_count; a.ws = (float*)workspace_dev; a.grad = grad_dev;
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(onf_train_sample_kernel, dim3((unsigned)n_samples), dim3(TS_THREADS), 0, st, a);
   NFOPP_HIP(hipGetLastError());
 
@@ -271,10 +298,7 @@ extern "C" int nfopp_onf_train_grad(const nfopp_onf_config* cfg, const float* pa
   add(g.off_w3 + H, g.fin, g.fin, a.w.rho, 1, a.w.in, g.fin);
   add(g.off_b3, 1, 1, a.w.rho, 1, -1, 0);
   add(g.off_we, 2 * g.n_enc, 2, a.w.de, g.n_enc, a.w.u, 2);
-  if (g.off_be >= 0) {
-    NFOPP_REQUIRE(n < MAX_SEG, "internal: too many gradient segments");
-    add(g.off_be, g.n_enc, 1, a.w.de, g.n_enc, -1, 0);
-  }
+  add(g.off_be, g.n_enc, 1, a.w.de, g.n_enc, -1, 0);
   NFOPP_REQUIRE(n <= MAX_SEG, "internal: too many gradient segments");
   r.n_seg = n; r.n_params = g.n_params; r.n_chunks = a.w.n_chunks; r.P = n_samples; r.ws = a.ws;
   r.partial_off = a.w.partial; r.loss_off = a.w.loss; r.grad = grad_dev;

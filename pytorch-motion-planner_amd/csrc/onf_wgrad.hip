@@ -1,0 +1,353 @@
+// ONF fitting step at scale: weight gradients as fp32-MFMA GEMMs over the sample axis.
+//
+// Replaces (reference, PyTorch-CPU + autograd): `loss.backward()` of `_optimize_collision_model`
+// nfop/nerf_opt_planner.py:83-89 when the number of samples is large (batched planning with a shared field:
+// P = B * (N + 109) samples per step, BASELINE config 5).  Small P keeps the per-sample path of csrc/onf_train.hip.
+//
+// Pipeline (all reductions in a fixed order -> bitwise reproducible, no float atomics):
+//   1. onf_fwd_bwd_kernel<.., TRAIN> (csrc/onf_fused.hip): forward + backward per sample on the MFMA chain, writes the
+//      per-sample factor matrices  in | h1 | h2 | dh1 | dh2 | de | u  (slot order, with a ones column and a rho row so
+//      that bias and W3 gradients fall out of the same GEMMs) and per-wave loss partials;
+//   2. onf_wgrad_kernel: persistent workgroups, 16-sample chunks staged into LDS as one combined row per sample
+//      (stride = 16 mod 32 -> conflict-free operand reads), 8*NKT+56 output tiles spread over 8 waves:
+//        G1 = dh1^T in   (dW1, db1, dW3[100:], db3)     G2 = dh2^T h1 (dW2, db2)
+//        G3 = de^T  u    (dWe, dbe, angle grads)        G4 = rho^T h2 (dW3[:100])
+//      next chunk prefetched into registers while the current one multiplies; per-workgroup partial tiles to HBM;
+//   3. onf_wgrad_reduce_kernel (sum over workgroups) and onf_wgrad_gather_kernel (slot -> parameter index).
+#include "onf_kernel.h"
+
+namespace nfopp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_THREADS = 512;
+constexpr int WG_WAVES = 8;
+constexpr int KC = 16;  // samples per LDS chunk (4 k-steps: every operand offset stays a ds_read immediate)
+constexpr int HS = 112; // hidden-side row length (7 tiles)
+
+template <int NKT>
+struct WgLayout {
+  static constexpr int WIN = 16 * NKT;
+  static constexpr int C_DH1 = 0, C_IN = HS, C_DH2 = C_IN + WIN, C_H1 = C_DH2 + HS, C_DE = C_H1 + HS,
+                       C_U = C_DE + WIN, C_H2 = C_U + 16, STRIDE = C_H2 + HS;  // = 464 + 2*WIN = 16 mod 32
+  static constexpr int NTILES = 8 * NKT + 56;
+  static constexpr int TPW = (NTILES + WG_WAVES - 1) / WG_WAVES;  // tiles per wave
+  static constexpr int F4_PER_SAMPLE = (4 * HS + 2 * WIN + 4) / 4;
+  static constexpr int F4_PER_THREAD = (KC * F4_PER_SAMPLE + WG_THREADS - 1) / WG_THREADS;
+  static constexpr size_t LDS_BYTES = size_t(KC) * STRIDE * 4;
+};
+
+struct WgradArgs {
+  const float* ws_in; const float* ws_h1; const float* ws_h2; const float* ws_dh1; const float* ws_dh2;
+  const float* ws_de; const float* ws_u;
+  long long P;
+  float* partial;  // [grid][NTILES][256]
+};
+
+// column (within the combined LDS row) and source pointer of float4 number c of a sample
+template <int NKT>
+__device__ __forceinline__ void f4_source(const WgradArgs& a, long long p, int c, const float** src, int* col) {
+  using W = WgLayout<NKT>;
+  constexpr int h4 = HS / 4, w4 = W::WIN / 4;
+  if (c < h4) { *src = a.ws_dh1 + p * HS + 4 * c; *col = W::C_DH1 + 4 * c; return; }
+  c -= h4;
+  if (c < w4) { *src = a.ws_in + p * W::WIN + 4 * c; *col = W::C_IN + 4 * c; return; }
+  c -= w4;
+  if (c < h4) { *src = a.ws_dh2 + p * HS + 4 * c; *col = W::C_DH2 + 4 * c; return; }
+  c -= h4;
+  if (c < h4) { *src = a.ws_h1 + p * HS + 4 * c; *col = W::C_H1 + 4 * c; return; }
+  c -= h4;
+  if (c < w4) { *src = a.ws_de + p * W::WIN + 4 * c; *col = W::C_DE + 4 * c; return; }
+  c -= w4;
+  if (c < 1) { *src = a.ws_u + p * 4; *col = W::C_U; return; }
+  c -= 1;
+  *src = a.ws_h2 + p * HS + 4 * c; *col = W::C_H2 + 4 * c;
+}
+
+template <int NKT>
+__global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArgs a) {
+  using W = WgLayout<NKT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const long long n_chunks = (a.P + KC - 1) / KC;
+
+  // operand pointers of this wave's tiles: row g of the chunk, column of the tile + lane; k-step s adds the immediate
+  // 4 * s * STRIDE
+  int pa[W::TPW], pb[W::TPW];  // 32-bit LDS float offsets
+#pragma unroll
+  for (int j = 0; j < W::TPW; ++j) {
+    int T = wave + WG_WAVES * j;
+    if (T >= W::NTILES) T = W::NTILES - 1;  // idle slot: recomputes the last tile, never written
+    int ac, bc;
+    if (T < 7 * NKT) { ac = W::C_DH1 + 16 * (T / NKT); bc = W::C_IN + 16 * (T % NKT); }
+    else if (T < 7 * NKT + 49) { const int q = T - 7 * NKT; ac = W::C_DH2 + 16 * (q / 7); bc = W::C_H1 + 16 * (q % 7); }
+    else if (T < 8 * NKT + 49) { ac = W::C_DE + 16 * (T - 7 * NKT - 49); bc = W::C_U; }
+    else { ac = W::C_DH2 + 96; bc = W::C_H2 + 16 * (T - 8 * NKT - 49); }
+    pa[j] = g * W::STRIDE + ac + i;
+    pb[j] = g * W::STRIDE + bc + i;
+  }
+  f32x4 acc[W::TPW];
+#pragma unroll
+  for (int j = 0; j < W::TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // zero the unused columns 4..15 of the u tile once
+  for (int k = tid; k < KC * 12; k += WG_THREADS) lds[(k / 12) * W::STRIDE + W::C_U + 4 + (k % 12)] = 0.0f;
+
+  f32x4 stage[W::F4_PER_THREAD];
+  auto prefetch = [&](long long chunk) {
+#pragma unroll
+    for (int k = 0; k < W::F4_PER_THREAD; ++k) {
+      const int idx = tid + k * WG_THREADS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < KC * W::F4_PER_SAMPLE) {
+        const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
+        const long long p = chunk * KC + q;
+        if (p < a.P) {
+          const float* src; int col;
+          f4_source<NKT>(a, p, c, &src, &col);
+          v = *reinterpret_cast<const f32x4*>(src);
+        }
+      }
+      stage[k] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < W::F4_PER_THREAD; ++k) {
+      const int idx = tid + k * WG_THREADS;
+      if (idx < KC * W::F4_PER_SAMPLE) {
+        const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
+        const float* src; int col;
+        f4_source<NKT>(a, 0, c, &src, &col);
+        *reinterpret_cast<f32x4*>(lds + q * W::STRIDE + col) = stage[k];
+      }
+    }
+  };
+
+  long long chunk = blockIdx.x;
+  if (chunk < n_chunks) prefetch(chunk);
+  for (; chunk < n_chunks; chunk += gridDim.x) {
+    __syncthreads();  // previous chunk fully consumed
+    commit();
+    __syncthreads();
+    if (chunk + gridDim.x < n_chunks) prefetch(chunk + gridDim.x);
+    constexpr int GRP = 7;  // tiles whose operands are in flight together
+#pragma unroll
+    for (int j0 = 0; j0 < W::TPW; j0 += GRP) {
+#pragma unroll
+      for (int s = 0; s < KC / 4; ++s) {
+        float av[GRP], bv[GRP];
+#pragma unroll
+        for (int j = j0; j < j0 + GRP && j < W::TPW; ++j) {
+          av[j - j0] = lds[pa[j] + 4 * s * W::STRIDE];
+          bv[j - j0] = lds[pb[j] + 4 * s * W::STRIDE];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = j0; j < j0 + GRP && j < W::TPW; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j - j0], bv[j - j0], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < W::TPW; ++j) {
+    const int T = wave + WG_WAVES * j;
+    if (T < W::NTILES) {
+      float* o = a.partial + ((long long)blockIdx.x * W::NTILES + T) * 256 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[64 * r] = acc[j][r];
+    }
+  }
+}
+
+// reduced[e] = sum over workgroups of partial[wg][e], fixed order
+__global__ __launch_bounds__(256) void onf_wgrad_reduce_kernel(const float* partial, float* reduced, int n_elems, int n_wg) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elems) return;
+  float s = 0.f;
+  for (int w = 0; w < n_wg; ++w) s += partial[(long long)w * n_elems + e];
+  reduced[e] = s;
+}
+
+// ---- slot maps (see csrc/onf_fused.hip for the layouts) --------------------------------------------------------
+__host__ __device__ inline int slot_layout_p(int f) {  // input features, h2 / dh2 (features < 96)
+  const int o = f & 31, tpar = (o >> 3) & 1, op = o - 8 * tpar, ap = op & ~3, r = op & 3;
+  const int g = ((ap >> 4) & 1) | (((ap >> 2) & 1) << 1);
+  return 16 * (2 * (f >> 5) + tpar) + 4 * g + r;
+}
+__host__ __device__ inline int slot_layout_q(int f) {  // h1 / dh1 (features < 96)
+  const int o = f & 15, aq = o & 12, r = o & 3;
+  const int g = ((aq >> 3) & 1) | (((aq >> 2) & 1) << 1);
+  return 16 * (f >> 4) + 4 * g + r;
+}
+__host__ __device__ inline int hidden_slot(int h, bool layout_q) {
+  if (h >= 96) return 96 + 4 * (h - 96);
+  return layout_q ? slot_layout_q(h) : slot_layout_p(h);
+}
+constexpr int AUG_HIDDEN_SLOT = 97;  // tile 6, g = 0, r = 1
+
+struct GatherArgs {
+  OnfGeom geom;
+  int nkt, aug_in_slot, n_loss_partials;
+  const float* params;
+  const float* reduced;       // [NTILES][256]
+  const float* loss_partial;
+  float* grad;                // [n_params + 2]
+  float count;
+};
+
+__device__ __forceinline__ float tile_elem(const float* reduced, int T, int rs, int cs) {
+  return reduced[T * 256 + (rs & 3) * 64 + (rs >> 2) * 16 + cs];
+}
+
+__global__ __launch_bounds__(256) void onf_wgrad_gather_kernel(const GatherArgs a) {
+  const OnfGeom& g = a.geom;
+  const int NKT = a.nkt;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int T_G2 = 7 * NKT, T_G3 = 7 * NKT + 49, T_G4 = 8 * NKT + 49;
+  if (o < g.n_params) {
+    float v = 0.f;
+    if (g.n_ang && o < g.off_ang_b + g.n_ang) {            // d/d angle bias = f_k * sum dz_k
+      const int k = o - g.off_ang_b, s = slot_layout_p(g.n_enc + k);
+      v = a.params[g.off_ang_f + k] * tile_elem(a.reduced, T_G3 + s / 16, s % 16, 2);
+    } else if (g.n_ang && o < g.off_ang_f + g.n_ang) {     // d/d frequency = sum dz_k (theta + b_k)
+      const int k = o - g.off_ang_f, s = slot_layout_p(g.n_enc + k);
+      v = tile_elem(a.reduced, T_G3 + s / 16, s % 16, 3) +
+          a.params[g.off_ang_b + k] * tile_elem(a.reduced, T_G3 + s / 16, s % 16, 2);
+    } else if (o < g.off_b1) {                             // W1[m][k]
+      const int q = o - g.off_w1, m = q / g.fin, k = q - m * g.fin;
+      const int rs = hidden_slot(m, true), cs = slot_layout_p(k);
+      v = tile_elem(a.reduced, (rs / 16) * NKT + cs / 16, rs % 16, cs % 16);
+    } else if (o < g.off_w2) {                             // b1[m]
+      const int rs = hidden_slot(o - g.off_b1, true), cs = a.aug_in_slot;
+      v = tile_elem(a.reduced, (rs / 16) * NKT + cs / 16, rs % 16, cs % 16);
+    } else if (o < g.off_b2) {                             // W2[m][k]
+      const int q = o - g.off_w2, m = q / NFOPP_HIDDEN, k = q - m * NFOPP_HIDDEN;
+      const int rs = hidden_slot(m, false), cs = hidden_slot(k, true);
+      v = tile_elem(a.reduced, T_G2 + (rs / 16) * 7 + cs / 16, rs % 16, cs % 16);
+    } else if (o < g.off_w3) {                             // b2[m]
+      const int rs = hidden_slot(o - g.off_b2, false), cs = AUG_HIDDEN_SLOT;
+      v = tile_elem(a.reduced, T_G2 + (rs / 16) * 7 + cs / 16, rs % 16, cs % 16);
+    } else if (o < g.off_b3) {                             // W3[j]
+      const int j = o - g.off_w3;
+      if (j < NFOPP_HIDDEN) {
+        const int cs = hidden_slot(j, false);
+        v = tile_elem(a.reduced, T_G4 + cs / 16, 1, cs % 16);
+      } else {
+        const int cs = slot_layout_p(j - NFOPP_HIDDEN);
+        v = tile_elem(a.reduced, 6 * NKT + cs / 16, 1, cs % 16);
+      }
+    } else if (o == g.off_b3) {
+      v = tile_elem(a.reduced, 6 * NKT + a.aug_in_slot / 16, 1, a.aug_in_slot % 16);
+    } else if (g.off_be < 0 || o < g.off_be) {             // We[f][c]
+      const int q = o - g.off_we, f = q >> 1, s = slot_layout_p(f);
+      v = tile_elem(a.reduced, T_G3 + s / 16, s % 16, q & 1);
+    } else {                                               // be[f]
+      const int s = slot_layout_p(o - g.off_be);
+      v = tile_elem(a.reduced, T_G3 + s / 16, s % 16, 2);
+    }
+    a.grad[o] = v;
+  }
+  if (o == 0) {  // mean BCE loss: per-wave partials in launch order
+    float s = 0.f;
+    for (int k = 0; k < a.n_loss_partials; ++k) s += a.loss_partial[k];
+    a.grad[g.n_params] = s;
+    a.grad[g.n_params + 1] = a.count;
+  }
+}
+
+// smallest zero-weight pad feature that the input slot map covers (tiles < NKT): carries the "ones" column
+static int find_aug_feature(int fin, int nkt) {
+  for (int f = fin; f < 32 * ((nkt + 1) / 2); ++f)
+    if (slot_layout_p(f) / 16 < nkt) return f;
+  return -1;
+}
+
+struct WgradWs {  // float offsets into the workspace
+  long long in, h1, h2, dh1, dh2, de, u, loss, partial, reduced, total;
+  int win, ntiles, grid_cap;
+};
+
+static WgradWs carve_wgrad(const OnfGeom& g, long long P) {
+  WgradWs w;
+  const int nkt = (g.fin + 15) / 16;
+  w.win = 16 * nkt;
+  w.ntiles = 8 * nkt + 56;
+  w.grid_cap = onf_train_grid_upper_bound();
+  long long o = 0;
+  w.in = o; o += P * w.win;
+  w.h1 = o; o += P * HS;
+  w.h2 = o; o += P * HS;
+  w.dh1 = o; o += P * HS;
+  w.dh2 = o; o += P * HS;
+  w.de = o; o += P * w.win;
+  w.u = o; o += P * 4;
+  w.loss = o; o += (long long)w.grid_cap * 8;
+  w.partial = o; o += (long long)w.grid_cap * w.ntiles * 256;
+  w.reduced = o; o += (long long)w.ntiles * 256;
+  w.total = o;
+  return w;
+}
+
+size_t wgrad_workspace_bytes(const OnfGeom& g, long long P) { return (size_t)carve_wgrad(g, P).total * sizeof(float); }
+
+template <int NKT>
+static int launch_wgrad(const WgradArgs& a, int grid, hipStream_t st) {
+  using W = WgLayout<NKT>;
+  static bool attr_set = false;
+  auto kern = onf_wgrad_kernel<NKT>;
+  if (!attr_set) {
+    NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)W::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG_THREADS), W::LDS_BYTES, st, a);
+  NFOPP_HIP(hipGetLastError());
+  return NFOPP_OK;
+}
+
+// gradient of the mean BCE loss over `count` samples (inv_count = 1 / count) into grad[n_params + 2]
+int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samples, const float* labels, long long P,
+                        float inv_count, float* grad, float* ws, hipStream_t st) {
+  const WgradWs w = carve_wgrad(g, P);
+  const int nkt = (g.fin + 15) / 16;
+  const int aug = find_aug_feature(g.fin, nkt);
+  NFOPP_REQUIRE(aug >= 0, "no pad feature available for the ones column (fin = %d)", g.fin);
+  OnfKernelArgs a = {};
+  a.geom = g; a.params = params; a.points = samples; a.n_points = P; a.out4 = nullptr;
+  a.labels = labels; a.inv_count = inv_count; a.aug_feature = aug;
+  a.ws_in = ws + w.in; a.ws_h1 = ws + w.h1; a.ws_h2 = ws + w.h2; a.ws_dh1 = ws + w.dh1; a.ws_dh2 = ws + w.dh2;
+  a.ws_de = ws + w.de; a.ws_u = ws + w.u; a.loss_partial = ws + w.loss;
+  int grid_fwd = 0;
+  int rc = launch_onf_train_kernel(a, st, &grid_fwd);
+  if (rc) return rc;
+
+  WgradArgs wa;
+  wa.ws_in = a.ws_in; wa.ws_h1 = a.ws_h1; wa.ws_h2 = a.ws_h2; wa.ws_dh1 = a.ws_dh1; wa.ws_dh2 = a.ws_dh2;
+  wa.ws_de = a.ws_de; wa.ws_u = a.ws_u; wa.P = P; wa.partial = ws + w.partial;
+  long long n_chunks = (P + KC - 1) / KC;
+  int grid = (int)(n_chunks < w.grid_cap ? n_chunks : w.grid_cap);
+  switch (nkt) {
+    case 14: rc = launch_wgrad<14>(wa, grid, st); break;
+    case 13: rc = launch_wgrad<13>(wa, grid, st); break;
+    case 8: rc = launch_wgrad<8>(wa, grid, st); break;
+    case 7: rc = launch_wgrad<7>(wa, grid, st); break;
+    default: set_error("unsupported ONF feature dimension %d", g.fin); return NFOPP_ERR_ARG;
+  }
+  if (rc) return rc;
+  const int n_elems = w.ntiles * 256;
+  hipLaunchKernelGGL(onf_wgrad_reduce_kernel, dim3((n_elems + 255) / 256), dim3(256), 0, st, ws + w.partial,
+                     ws + w.reduced, n_elems, grid);
+  NFOPP_HIP(hipGetLastError());
+  GatherArgs ga;
+  ga.geom = g; ga.nkt = nkt; ga.aug_in_slot = slot_layout_p(aug); ga.n_loss_partials = grid_fwd * 8;
+  ga.params = params; ga.reduced = ws + w.reduced; ga.loss_partial = ws + w.loss; ga.grad = grad; ga.count = (float)P;
+  hipLaunchKernelGGL(onf_wgrad_gather_kernel, dim3((g.n_params + 255) / 256), dim3(256), 0, st, ga);
+  NFOPP_HIP(hipGetLastError());
+  return NFOPP_OK;
+}
+
+}  // namespace nfopp

@@ -50,6 +50,8 @@ _SIGNATURES = {
     "nfopp_onf_train_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(OnfConfigC), ctypes.c_int64]),
     "nfopp_onf_train_grad": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, _P, ctypes.c_int64, ctypes.c_float,
                                             _P, _P, ctypes.c_size_t, _P]),
+    "nfopp_onf_train_grad_ex": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, _P, ctypes.c_int64, ctypes.c_float,
+                                               _P, _P, ctypes.c_size_t, ctypes.c_int32, _P]),
     "nfopp_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
 }

@@ -263,3 +263,54 @@ def test_full_size_batch_replicates_single_trajectory():
     eng.reparametrize()
     tr2 = eng.traj.cpu().numpy()
     assert np.array_equal(tr2, np.repeat(tr2[:1], B, axis=0))
+
+
+def _train_grad(onf, x, y, path, inv_count=None):
+    lib = nfopp.load_library()
+    from nfopp import _lib
+    P = x.shape[0]
+    c = onf.config_c()
+    need = lib.nfopp_onf_train_workspace_bytes(c, P)
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device="cuda")
+    grad = torch.zeros(onf.n_params + 2, device="cuda")
+    _lib.check(lib.nfopp_onf_train_grad_ex(c, _lib.ptr(onf.flat_parameters), _lib.ptr(x), _lib.ptr(y), P,
+                                           1.0 / P if inv_count is None else inv_count, _lib.ptr(grad), _lib.ptr(ws),
+                                           ws.numel() * 4, path, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_onf_training_paths_vs_golden(path):
+    """Both implementations of the fitting-step gradient (per-sample kernels / MFMA GEMM path) against the reference."""
+    z = load_golden("g7_onf_train.npz")
+    onf, cfg = gc.make_onf(z["cfg"], z["params_before"])
+    x = torch.tensor(z["x"].astype(F32), device="cuda")
+    y = torch.tensor(z["labels"].astype(F32), device="cuda")
+    g = _train_grad(onf, x, y, path)
+    assert abs(float(g[-2]) - float(z["loss"])) < 2e-6
+    assert g[-1] == x.shape[0]
+    assert max_abs(g[:-2], z["grad"]) < 3e-6 * max(1.0, float(np.abs(z["grad"]).max()))
+
+
+@pytest.mark.parametrize("tag,P", [("a", 5000), ("b", 3001), ("c", 2500)])
+def test_onf_training_mfma_path_vs_oracle_large(tag, P):
+    """Ragged sample counts through the automatic (MFMA) path, three field configurations, vs the oracle."""
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z[tag + "_cfg"], z[tag + "_params"])
+    rng = np.random.default_rng(P)
+    x = z[tag + "_x"][rng.integers(0, len(z[tag + "_x"]), P)].copy()
+    x += rng.normal(0, 0.05, x.shape).astype(F32)
+    y = (rng.uniform(size=P) < 0.4).astype(F32)
+    g_auto = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 0)
+    g_ps = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 1)
+    loss, _, gref = orc.onf_train_grads(z[tag + "_params"], cfg, x, y)
+    scale = max(1.0, float(np.abs(gref).max()))
+    assert abs(float(g_auto[-2]) - float(loss)) < 5e-6 * max(1.0, abs(float(loss)))
+    assert max_abs(g_auto[:-2], gref) < 2e-5 * scale
+    assert max_abs(g_ps[:-2], gref) < 2e-5 * scale
+    # the two device paths differ only by summation order
+    assert max_abs(g_auto[:-2], g_ps[:-2]) < 2e-5 * scale
+    # bitwise reproducible
+    g_again = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 0)
+    assert np.array_equal(g_auto, g_again)
