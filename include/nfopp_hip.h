@@ -131,6 +131,45 @@ int nfopp_onf_train_grad_ex(const nfopp_onf_config* cfg, const float* params_dev
                             const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
                             void* workspace_dev, size_t workspace_bytes, int32_t path, void* stream);
 
+/* ---- continuous ONF learning over a batch: ground truth and sample generation on the device --------------------
+ * Ground-truth checkers (labels_dev[p] = 1.0 in collision, 0.0 free); bounds4 (host, may be NULL) = xmin,xmax,ymin,ymax
+ * of nfop/collision_checker/collision_checker.py:12-19.
+ *   circle:    any |pose.xy - obstacle| < radius                 nfop/collision_checker/circle_collision_checker.py:11-14
+ *   rectangle: any obstacle inside box4 = (x0,x1,y0,y1) in the robot frame   .../rectangle_collision_checker.py:11-26
+ *   grid:      uint8 occupancy image, cell = int((x - origin - cell/2)/cell); outside the image = collision
+ *              (MapCollisionChecker, notebooks/onf_planner_image_map.ipynb cell 2) */
+int nfopp_check_collision_circle(const float* poses_dev, int64_t n, int32_t pose_dim, const float* obstacles_dev,
+                                 int32_t n_obstacles, float radius, const float* bounds4, float* labels_dev,
+                                 void* stream);
+int nfopp_check_collision_rectangle(const float* poses_dev, int64_t n, const float* obstacles_dev, int32_t n_obstacles,
+                                    const float* box4, const float* bounds4, float* labels_dev, void* stream);
+int nfopp_check_collision_grid(const float* poses_dev, int64_t n, int32_t pose_dim, const uint8_t* grid_dev,
+                               int32_t rows, int32_t cols, float origin_x, float origin_y, float cell_size,
+                               float* labels_dev, void* stream);
+
+/* Training-pose generation for every trajectory of a batch (nfop/nerf_opt_planner.py:101-120,135-141,
+ * constrained:57-61,173-176).  Per trajectory: N-1 interpolated poses of the PREVIOUS trajectory -> "course" copies
+ * (sigma course/angle) written to samples[b][0..N-2], "fine" copies appended to the candidate list behind the
+ * retained pool (pool_count = 0 on the first step, pool_cap afterwards), n_field uniform field poses written to
+ * samples[b][N-1+pool_cap ...].  Layouts: cand [B, pool_cap+N-1, D], samples [B, N-1+pool_cap+n_field, D].
+ * Draws: Philox4x32-10 keyed by seed, counter (index, stream, trajectory, rng_offset). */
+int nfopp_sample_candidates(const float* prev_traj_dev, int64_t batch, int32_t n_waypoints, int32_t dim,
+                            int32_t pool_cap, int32_t pool_count, int32_t n_field, float course_sigma, float fine_sigma,
+                            float angle_sigma, const float* bounds4, uint64_t seed, uint64_t rng_offset,
+                            int64_t traj_index_offset, const float* pool_dev, const float* pool_age_dev,
+                            float* cand_dev, float* cand_age_dev, float* samples_dev, void* stream);
+
+/* Retained-pool resampling (nfop/nerf_opt_planner.py:122-133): weights sigmoid(logit)*exp(-0.03 age)+1e-6, pool_cap
+ * candidates kept WITHOUT replacement with probability proportional to the weights (exponential race), ages + 1.
+ * The first n_candidates of cand_stride (= pool_cap + N - 1) candidate slots per trajectory are valid;
+ * onf_out4_dev [B, cand_stride, 4] = nfopp_onf_eval_points on cand_dev.  The new pool is also written to
+ * samples[b][sample_offset ...] (sample_stride = poses per trajectory in the samples buffer). */
+int nfopp_resample_pool(int64_t batch, int32_t n_candidates, int32_t cand_stride, int32_t pool_cap, int32_t dim,
+                        int32_t sample_stride,
+                        int32_t sample_offset, uint64_t seed, uint64_t rng_offset, int64_t traj_index_offset,
+                        const float* cand_dev, const float* cand_age_dev, const float* onf_out4_dev, float* pool_dev,
+                        float* pool_age_dev, float* samples_dev, void* stream);
+
 /* torch.optim.Adam single-tensor update on a flat buffer (used for the ONF weights after the gradient
  * all-reduce): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps). */
 int nfopp_adam_step(float* param_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, float beta2,

@@ -507,3 +507,96 @@ def initialize_trajectory(start, goal, n):
     ga = F32(wrap_angle(goal[2] - start[2]) + start[2])
     out[:, 2] = linspace_f32(start[2], ga, n + 2)[1:-1]
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# batched sample generation for continuous ONF learning (device restatement of nfop/nerf_opt_planner.py:101-141 with a
+# counter-based RNG; csrc/sampling.hip) -- same Philox stream, so the checks are exact up to libm rounding
+STREAM_T, STREAM_COURSE, STREAM_FINE, STREAM_FIELD, STREAM_KEY = 1, 2, 3, 4, 5
+
+
+def philox_uniform(seed, ctr_lo, ctr_hi):
+    """Philox4x32-10, output word 0 -> uniform [0, 1) with 24 random bits (csrc/common.h philox_uniform)."""
+    ctr_lo = np.asarray(ctr_lo, np.uint64)
+    ctr_hi = np.broadcast_to(np.asarray(ctr_hi, np.uint64), ctr_lo.shape)
+    mask = np.uint64(0xFFFFFFFF)
+    c0, c1 = ctr_lo & mask, ctr_lo >> np.uint64(32)
+    c2, c3 = ctr_hi & mask, ctr_hi >> np.uint64(32)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    m0, m1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    for _ in range(10):
+        p0, p1 = m0 * c0, m1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return ((c0 >> np.uint64(8)).astype(np.float64) * 2.0 ** -24).astype(F32)
+
+
+def draw_uniform(seed, traj, idx, offset, stream):
+    lo = np.asarray(idx, np.uint64) | (np.uint64(stream) << np.uint64(32))
+    hi = (np.uint64(traj) << np.uint64(24)) ^ np.uint64(offset)
+    return philox_uniform(seed, lo, hi)
+
+
+def draw_normal(seed, traj, idx, offset, stream):
+    idx = np.asarray(idx, np.uint64)
+    u1 = (F32(1) - draw_uniform(seed, traj, 2 * idx, offset, stream)).astype(F32)
+    u2 = draw_uniform(seed, traj, 2 * idx + 1, offset, stream)
+    return (np.sqrt(F32(-2) * np.log(u1)) * np.cos(TWO_PI * u2)).astype(F32)
+
+
+def sample_candidates(prev_traj, pool, pool_age, cap, n_field, course_sigma, fine_sigma, angle_sigma, bounds, seed,
+                      offset, traj_index_offset=0):
+    """-> (cand [B,C,D], cand_age [B,C], samples [B,S,D]) with the pool slot of `samples` left at zero."""
+    prev_traj = np.asarray(prev_traj, F32)
+    B, N, D = prev_traj.shape
+    pool_n = 0 if pool is None else cap
+    C, S = cap + N - 1, (N - 1) + cap + n_field
+    cand, cage, smp = np.zeros((B, C, D), F32), np.zeros((B, C), F32), np.zeros((B, S, D), F32)
+    j = np.arange(N - 1)
+    for b in range(B):
+        tg = traj_index_offset + b
+        if pool_n:
+            cand[b, :cap], cage[b, :cap] = pool[b], pool_age[b]
+        t = draw_uniform(seed, tg, j, offset, STREAM_T)[:, None]
+        pos = (prev_traj[b, 1:] * (F32(1) - t) + prev_traj[b, :-1] * t).astype(F32)
+        for d in range(D):
+            sc, sf = (course_sigma, fine_sigma) if d < 2 else (angle_sigma, angle_sigma)
+            smp[b, :N - 1, d] = pos[:, d] + draw_normal(seed, tg, D * j + d, offset, STREAM_COURSE) * F32(sc)
+            cand[b, pool_n:pool_n + N - 1, d] = pos[:, d] + draw_normal(seed, tg, D * j + d, offset, STREAM_FINE) * F32(sf)
+        r = np.arange(n_field)
+        lo_x, hi_x, lo_y, hi_y = (F32(v) for v in bounds)
+        f0 = (N - 1) + cap
+        smp[b, f0:, 0] = lo_x + draw_uniform(seed, tg, D * r, offset, STREAM_FIELD) * (hi_x - lo_x)
+        smp[b, f0:, 1] = lo_y + draw_uniform(seed, tg, D * r + 1, offset, STREAM_FIELD) * (hi_y - lo_y)
+        if D == 3:
+            smp[b, f0:, 2] = draw_uniform(seed, tg, D * r + 2, offset, STREAM_FIELD) * TWO_PI
+    return cand[:, :pool_n + N - 1], cage[:, :pool_n + N - 1], smp
+
+
+def resample_pool(cand, cand_age, logits, cap, seed, offset, traj_index_offset=0):
+    """Exponential-race weighted sampling without replacement -> (pool [B,cap,D], age [B,cap], chosen indices)."""
+    cand, cand_age, logits = np.asarray(cand, F32), np.asarray(cand_age, F32), np.asarray(logits, F32)
+    B, C, D = cand.shape
+    pool, age, chosen = np.zeros((B, cap, D), F32), np.zeros((B, cap), F32), np.zeros((B, cap), np.int64)
+    c = np.arange(C)
+    for b in range(B):
+        w = (sigmoid(logits[b]) * np.exp(F32(-0.03) * cand_age[b]) + F32(1e-6)).astype(F32)
+        u = (F32(1) - draw_uniform(seed, traj_index_offset + b, c, offset, STREAM_KEY)).astype(F32)
+        key = (-np.log(u) / w).astype(F32)
+        order = np.lexsort((c, key))[:cap]
+        chosen[b], pool[b], age[b] = order, cand[b, order], cand_age[b, order] + F32(1)
+    return pool, age, chosen
+
+
+def grid_check(xy, grid, origin_x, origin_y, cell):
+    """MapCollisionChecker (notebooks/onf_planner_image_map.ipynb cell 2), fp32 arithmetic like the device kernel."""
+    xy = np.asarray(xy, F32)
+    rows, cols = grid.shape
+    ix = ((xy[:, 0] - F32(origin_x) - F32(cell) / F32(2)) / F32(cell)).astype(np.int32)
+    iy = ((xy[:, 1] - F32(origin_y) - F32(cell) / F32(2)) / F32(cell)).astype(np.int32)
+    inside = (ix >= 0) & (iy >= 0) & (iy < rows - 1) & (ix < cols - 1)
+    out = np.ones(len(xy), bool)
+    out[inside] = grid[iy[inside], ix[inside]] > 0
+    return out

@@ -9,11 +9,12 @@ from .factory import DEFAULT_PARAMETERS, PlannerFactory, UniversalFactory
 from .host_utils import (AstarTrajectoryInitializer, AttributeDict, CircleCollisionChecker,
                          CircleDirectedCollisionChecker, CollisionChecker, Position2, RectangleCollisionChecker,
                          TrajectoryInitializer)
+from .learning import BatchSampler, DeviceCircleChecker, DeviceGridChecker, DeviceRectangleChecker
 from .onf_model import ONF
 from .planner import ConstrainedNERFOptPlanner, ContinuousPlanner, NERFOptPlanner
 
 __all__ = [
-    "BatchPlanner", "OnfFitter", "shard_range", "straight_line_init", "LIB_PATH", "NfoppError", "load_library", "TrajectoryEngine", "TrajectoryHyper", "band_of", "inverse_hessian",
+    "BatchPlanner", "BatchSampler", "DeviceCircleChecker", "DeviceGridChecker", "DeviceRectangleChecker", "OnfFitter", "shard_range", "straight_line_init", "LIB_PATH", "NfoppError", "load_library", "TrajectoryEngine", "TrajectoryHyper", "band_of", "inverse_hessian",
     "DEFAULT_PARAMETERS", "PlannerFactory", "UniversalFactory", "AstarTrajectoryInitializer", "AttributeDict",
     "CircleCollisionChecker", "CircleDirectedCollisionChecker", "CollisionChecker", "Position2",
     "RectangleCollisionChecker", "TrajectoryInitializer", "ONF", "ConstrainedNERFOptPlanner", "ContinuousPlanner",

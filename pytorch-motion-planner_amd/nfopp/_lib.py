@@ -52,6 +52,19 @@ _SIGNATURES = {
                                             _P, _P, ctypes.c_size_t, _P]),
     "nfopp_onf_train_grad_ex": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, _P, ctypes.c_int64, ctypes.c_float,
                                                _P, _P, ctypes.c_size_t, ctypes.c_int32, _P]),
+    "nfopp_check_collision_circle": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_float,
+                                                    ctypes.POINTER(ctypes.c_float), _P, _P]),
+    "nfopp_check_collision_rectangle": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int32,
+                                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _P, _P]),
+    "nfopp_check_collision_grid": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P]),
+    "nfopp_sample_candidates": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                               ctypes.POINTER(ctypes.c_float), ctypes.c_uint64, ctypes.c_uint64,
+                                               ctypes.c_int64, _P, _P, _P, _P, _P, _P]),
+    "nfopp_resample_pool": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, _P, _P, _P, _P,
+                                           _P, _P, _P]),
     "nfopp_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
 }

@@ -107,16 +107,28 @@ class OnfFitter(object):
 
 
 class BatchPlanner(object):
-    """B trajectories, one shared ONF, one GPU.  `step()` = ONE `_optimize_trajectory` per trajectory plus the
-    periodic reparametrisation, i.e. the frozen-ONF planner step of nfop/nerf_opt_planner.py:60-71 for the batch."""
+    """B trajectories, one shared ONF, one GPU.  `step()` = the planner step of nfop/nerf_opt_planner.py:60-71 for the
+    whole batch: [ONF fit on freshly sampled poses, when a ground-truth `checker` is given] -> one
+    `_optimize_trajectory` per trajectory -> periodic reparametrisation.  Without a checker the field is frozen."""
 
     def __init__(self, onf, batch, n_waypoints, hyper, velocity_hessian_weight=0.5, reparametrize_trajectory_freq=10,
-                 device="cuda", seed=0, traj_index_offset=0):
+                 device="cuda", seed=0, traj_index_offset=0, checker=None, fit_lr=2e-2, fit_betas=(0.9, 0.9),
+                 optimize_collision_model_freq=1, trajectory_random_offset=0.02, course_random_offset=1.5,
+                 angle_offset=0.0, random_field_points=10, collision_point_count=100, group=None):
         self.engine = TrajectoryEngine(onf, batch, n_waypoints, onf.point_dim, hyper, velocity_hessian_weight, device,
                                        seed=seed, traj_index_offset=traj_index_offset)
         self.onf = onf
         self.reparam_freq = int(reparametrize_trajectory_freq)
         self.step_count = 0
+        self.checker = checker
+        self.fit_freq = int(optimize_collision_model_freq)
+        self.sampler = self.fitter = self._prev = None
+        if checker is not None:
+            from .learning import BatchSampler
+            self.sampler = BatchSampler(onf, batch, n_waypoints, course_random_offset, trajectory_random_offset,
+                                        angle_offset, random_field_points, collision_point_count, device,
+                                        seed=seed + 1, traj_index_offset=traj_index_offset)
+            self.fitter = OnfFitter(onf, fit_lr, fit_betas, group=group)
 
     def init(self, starts, goals, boundaries, trajectories=None):
         eng = self.engine
@@ -133,8 +145,22 @@ class BatchPlanner(object):
                 buf.zero_()
         eng.adam_step = 0
         self.step_count = 0
+        self._prev = None
+
+    def fit_field(self):
+        """One `_optimize_collision_model` over the batch (nerf:76-91): poses from the PREVIOUS trajectories, labels
+        from the device checker, gradient all-reduced over the process group, identical Adam on every rank."""
+        eng = self.engine
+        if self._prev is None:
+            self._prev = eng.traj.detach().clone()
+        samples = self.sampler.draw(self._prev, eng.hyper.bounds)
+        self._prev.copy_(eng.traj)
+        labels = self.checker.labels(samples, out=self.sampler.labels)
+        return self.fitter.step(samples, labels)
 
     def step(self, t=None, want_terms=False):
+        if self.checker is not None and self.step_count % self.fit_freq == 0:
+            self.fit_field()
         self.engine.optimize_trajectory(t, want_terms=want_terms)
         if self.step_count % self.reparam_freq == 0:
             self.engine.reparametrize()

@@ -1,0 +1,96 @@
+"""GPU tests of the continuous-learning helpers (csrc/sampling.hip, nfopp/learning.py) against the oracle, which
+restates the same Philox stream: checks are exact up to libm rounding of log/cos/exp."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, max_abs
+
+pytestmark = pytest.mark.gpu
+
+gc = pytest.importorskip("gpu_common")
+import nfopp  # noqa: E402
+from oracle import nfopp_oracle as orc  # noqa: E402
+
+F32 = np.float32
+
+
+def test_device_checkers_vs_reference_labels():
+    z = load_golden("g11_init_checkers.npz")
+    poses = torch.tensor(z["poses"].astype(F32), device="cuda")
+    rc = nfopp.DeviceRectangleChecker(z["car_obstacles"], (-0.3, 0.2, -0.3, 0.2), (0, 3, 0, 3))
+    cd = nfopp.DeviceCircleChecker(z["corridor_obstacles"], 0.3, (0, 3, 0, 3))
+    got_r = rc.labels(poses).cpu().numpy().astype(np.uint8)
+    got_c = cd.labels(poses).cpu().numpy().astype(np.uint8)
+    assert np.array_equal(got_c, z["circle_truth"])       # reference labels (float64 numpy) reproduced exactly
+    assert np.array_equal(got_r, z["rect_truth"])
+    assert np.array_equal(cd.labels(poses[:, :2].contiguous()).cpu().numpy().astype(np.uint8), z["circle_truth"])
+    rng = np.random.default_rng(3)
+    grid = (rng.uniform(size=(60, 80)) < 0.3).astype(np.uint8) * 255
+    xy = rng.uniform(-1, 9, (5000, 2)).astype(F32)
+    gchk = nfopp.DeviceGridChecker(grid, -0.5, 0.25, 0.1)
+    got = gchk.labels(torch.tensor(xy, device="cuda")).cpu().numpy().astype(bool)
+    assert np.array_equal(got, orc.grid_check(xy, grid, -0.5, 0.25, 0.1))
+    assert 0.2 < got.mean() < 1.0
+    assert cd.labels(torch.zeros(0, 3, device="cuda")).shape == (0,)
+
+
+@pytest.mark.parametrize("D,tag", [(3, "a"), (2, "c")])
+def test_batch_sampler_vs_oracle_and_shard_invariance(D, tag):
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z[tag + "_cfg"], z[tag + "_params"])
+    rng = np.random.default_rng(D)
+    B, N, cap, nf = 5, 60, 40, 10
+    prev = rng.uniform(0.2, 2.8, (B, N, D)).astype(F32)
+    bounds = (-0.1, 3.1, -0.1, 3.1)
+    sm = nfopp.BatchSampler(onf, B, N, 1.5, 0.02, 0.3, nf, cap, seed=21)
+    prev_d = torch.tensor(prev, device="cuda")
+    s1 = sm.draw(prev_d, bounds).cpu().numpy().reshape(B, -1, D)
+    cand, age, smp = orc.sample_candidates(prev, None, None, cap, nf, 1.5, 0.02, 0.3, bounds, 21, 0)
+    assert max_abs(s1[:, :N - 1], smp[:, :N - 1]) < 2e-5          # course (Box-Muller: log/cos rounding)
+    assert max_abs(s1[:, N - 1 + cap:], smp[:, N - 1 + cap:]) < 1e-6
+    assert max_abs(sm.cand.cpu().numpy()[:, :N - 1], cand) < 2e-6
+    logits = sm.cand_out.cpu().numpy()[:, :N - 1, 0]
+    pool, page, chosen = orc.resample_pool(cand, age, logits, cap, 21, 0)
+    got_pool = sm.pool.cpu().numpy()
+    # same candidates chosen (as sets: ordering inside the pool is irrelevant), same ages
+    for b in range(B):
+        assert max_abs(np.sort(got_pool[b].sum(1)), np.sort(pool[b].sum(1))) < 1e-5
+    assert (sm.pool_age.cpu().numpy() == 1).all()
+    assert max_abs(s1[:, N - 1:N - 1 + cap], got_pool) == 0
+    # second draw: pool carried, ages grow
+    s2 = sm.draw(prev_d, bounds)
+    ages = sm.pool_age.cpu().numpy()
+    assert set(np.unique(ages)) <= {1.0, 2.0} and (ages == 2).any()
+    # shard invariance: trajectories 3..4 as their own shard give the same poses
+    sm2 = nfopp.BatchSampler(onf, 2, N, 1.5, 0.02, 0.3, nf, cap, seed=21, traj_index_offset=3)
+    t1 = sm2.draw(prev_d[3:].contiguous(), bounds).cpu().numpy().reshape(2, -1, D)
+    assert np.array_equal(t1, s1[3:])
+
+
+def test_batch_planner_learns_the_field_while_planning():
+    """Continuous mode end to end on one GPU: the shared field's BCE loss falls while 64 trajectories are optimised."""
+    torch.random.manual_seed(5)
+    onf = nfopp.ONF(0, 1, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to("cuda")
+    rng = np.random.default_rng(0)
+    obstacles = np.stack([np.full(10, 1.5), np.linspace(0.5, 2.5, 10)], 1)
+    checker = nfopp.DeviceCircleChecker(obstacles, 0.3, (0, 3, 0, 3))
+    B, N = 64, 128
+    bounds = (-0.1, 3.1, -0.1, 3.1)
+    starts = np.concatenate([rng.uniform(0.2, 0.8, (B, 1)), rng.uniform(0.3, 2.7, (B, 1)), rng.uniform(-1, 1, (B, 1))], 1)
+    goals = np.concatenate([rng.uniform(2.2, 2.8, (B, 1)), rng.uniform(0.3, 2.7, (B, 1)), rng.uniform(-1, 1, (B, 1))], 1)
+    hyper = nfopp.TrajectoryHyper(collision_weight=1, constraint_deltas_weight=20, multipliers_lr=0.1, bounds=bounds)
+    planner = nfopp.BatchPlanner(onf, B, N, hyper, checker=checker, fit_lr=5e-2, angle_offset=0.3, seed=3)
+    planner.init(starts.astype(F32), goals.astype(F32), bounds)
+    losses = []
+    for k in range(60):
+        planner.step()
+        losses.append(float(planner.fitter.last_loss))
+    paths = planner.get_paths()
+    assert np.isfinite(paths).all() and paths.shape == (B, N + 2, 3)
+    assert np.mean(losses[-10:]) < 0.6 * np.mean(losses[:5])
+    assert planner.sampler.pool_full and planner.fitter.step_count == 60
+    # the learnt field separates free space from the wall
+    probe = torch.tensor([[1.5, 1.5, 0.0], [0.5, 1.5, 0.0], [2.5, 0.4, 0.0]], device="cuda")
+    logit = onf(probe).cpu().numpy()[:, 0]
+    assert logit[0] > 0 > logit[1] and logit[2] < 0
