@@ -127,7 +127,13 @@ def main():
     ap.add_argument("--fit-iters", type=int, default=300)
     ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--workload", choices=("cfg3", "cfg5"), default="cfg3",
+                    help="cfg3 (default, the headline): 4096x256 frozen field.  cfg5: 4096x512 per GPU with continuous "
+                         "ONF learning every step (device sampling + checker + MFMA fit + gradient all-reduce)")
     args = ap.parse_args()
+    global N_WAYPOINTS
+    if args.workload == "cfg5":
+        N_WAYPOINTS = 512
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -147,12 +153,17 @@ def main():
     starts = free_poses(rng, world * B, obstacles, radius)
     goals = free_poses(rng, world * B, obstacles, radius)
     lo, hi = nfopp.shard_range(world * B, rank, world)
+    checker = None
+    if args.workload == "cfg5":   # continuous learning: ground truth on the device, forward-only constraints on
+        checker = nfopp.DeviceCircleChecker(obstacles, radius, BOUNDS, device=device)
     planner = nfopp.BatchPlanner(onf, hi - lo, N, bench_hyper(), velocity_hessian_weight=0.5, device=device, seed=100,
-                                 traj_index_offset=lo)
+                                 traj_index_offset=lo, checker=checker, fit_lr=2e-2, angle_offset=0.3)
     planner.init(starts[lo:hi], goals[lo:hi], BOUNDS)
     eng = planner.engine
 
     def one_step(ev=None):
+        if checker is not None and planner.step_count % planner.fit_freq == 0:
+            planner.fit_field()
         if ev is not None:
             ev[0].record()
         eng.collision_eval()
@@ -193,14 +204,18 @@ def main():
             "metric": "waypoint-evals/sec", "value": world * B * N * args.steps / elapsed, "unit": "waypoint-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] per GPU: %d trajectories x %d waypoints, random-obstacle map "
-                                   "(300 discs r=1.5 on 100x100), SE(2) constrained planner, frozen pre-fitted ONF "
-                                   "(F=220, fit loss %.3f)" % (B, N, fit_loss),
+            "config": {"workload": ("BASELINE configs[2] per GPU: %d trajectories x %d waypoints, random-obstacle map "
+                                    "(300 discs r=1.5 on 100x100), SE(2) constrained planner, frozen pre-fitted ONF "
+                                    "(F=220, fit loss %.3f)" % (B, N, fit_loss)) if checker is None else
+                                   ("BASELINE configs[4] per GPU: %d trajectories x %d waypoints, forward-only constraints, "
+                                    "continuous ONF learning every step on %d device-sampled poses per GPU, gradient "
+                                    "all-reduce over ranks (last fit loss %.3f)"
+                                    % (B, N, planner.sampler.B * planner.sampler.S, float(planner.fitter.last_loss))),
                        "trajectories_per_gpu": B, "waypoints": N, "global_batch": world * B,
-                       "parallelism": "trajectory shards, no data-path collective", "paths_finite": finite,
+                       "parallelism": "trajectory shards, no data-path collective" if checker is None else "trajectory shards + one all-reduce of the 33163-float ONF gradient buffer per step", "paths_finite": finite,
                        "planner_steps_per_s": args.steps / elapsed},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(B, N),
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(B, N) if checker is None else None,
                          "kernel": "onf_fwd_bwd_kernel<14,2>", "kernel_ms": k1_ms,
                          "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE},
         }

@@ -81,6 +81,11 @@ int64_t nfopp_onf_param_count(const nfopp_onf_config* cfg);
 int nfopp_onf_eval_points(const nfopp_onf_config* cfg, const float* params_dev, const float* points_dev,
                           int64_t n_points, float* out4_dev, void* stream);
 
+/* Forward only (the backward half of the kernel is skipped): out4_dev [P, 4] = logit, 0, 0, 0.  Used where the
+ * reference evaluates the field without gradients (nfop/nerf_opt_planner.py:98-99,122-125, plotting). */
+int nfopp_onf_eval_logits(const nfopp_onf_config* cfg, const float* params_dev, const float* points_dev,
+                          int64_t n_points, float* out4_dev, void* stream);
+
 /* Fused collision-point sampling + ONF forward + input gradient along a batch of trajectories: the ONF part
  * of `trajectory_loss` (constrained:78-85 for D = 3, nfop/nerf_opt_planner.py:113-117,157-169 for D = 2).
  *   traj_dev [B, N, D]   interior waypoints;  sample j of trajectory b lies between waypoints j and j+1

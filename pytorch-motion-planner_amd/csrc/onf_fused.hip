@@ -125,8 +125,12 @@ __device__ __forceinline__ f32x2 features2(f32x2 wx, f32x2 wy, f32x2 b, f32x2 fr
   return sin_halfturns2(arg, DERIV ? qh + splat2(NFOPP_Q_UNIT) : qh);
 }
 
-template <int NKT, int NT, bool TRAIN>
+// MODE 0: forward + input gradient (planner step)   1: training pass (factor matrices for the weight gradients)
+// MODE 2: forward only (logits: pool-candidate weights, `ONF.forward`)
+template <int NKT, int NT, int MODE>
 __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernelArgs a) {
+  constexpr bool TRAIN = MODE == 1;
+  constexpr bool FWD_ONLY = MODE == 2;
   using L = Lds<NKT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds<NKT, TRAIN>(lds, a);
@@ -393,6 +397,14 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
       }
     }
 
+    if (FWD_ONLY) {
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl)
+        if (g == 0 && pidx[tl] < a.n_points)
+          *reinterpret_cast<f32x4*>(a.out4 + pidx[tl] * 4) = f32x4{logit[tl], 0.f, 0.f, 0.f};
+      continue;
+    }
+
     // ---------------------------------------------------------------- L2T: dh1 = (W2^T dh2) * [a1 > 0]
     {
       f32x4 accd[NT][HT];
@@ -560,11 +572,11 @@ static int query_cus() {
   return g_num_cus;
 }
 
-template <int NKT, int NT, bool TRAIN = false>
+template <int NKT, int NT, int MODE = 0>
 static int launch_t(const OnfKernelArgs& a, hipStream_t stream, int* grid_out = nullptr) {
   using L = Lds<NKT>;
   static bool attr_set = false;
-  auto kern = onf_fwd_bwd_kernel<NKT, NT, TRAIN>;
+  auto kern = onf_fwd_bwd_kernel<NKT, NT, MODE>;
   if (!attr_set) {
     NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)L::BYTES));
@@ -596,15 +608,30 @@ int launch_onf_kernel(const OnfKernelArgs& a, hipStream_t stream) {
   }
 }
 
+int launch_onf_logits_kernel(const OnfKernelArgs& a, hipStream_t stream) {
+  if (a.n_points <= 0) return NFOPP_OK;
+  const int nkt = (a.geom.fin + 15) / 16;
+  const bool small = a.n_points < (long long)query_cus() * WAVES * 16 * 2;
+  switch (nkt) {
+    case 14: return small ? launch_t<14, 1, 2>(a, stream) : launch_t<14, 2, 2>(a, stream);
+    case 13: return small ? launch_t<13, 1, 2>(a, stream) : launch_t<13, 2, 2>(a, stream);
+    case 8: return launch_t<8, 1, 2>(a, stream);
+    case 7: return launch_t<7, 1, 2>(a, stream);
+    default:
+      set_error("unsupported ONF feature dimension %d", a.geom.fin);
+      return NFOPP_ERR_ARG;
+  }
+}
+
 // training forward/backward pass (factor matrices for csrc/onf_wgrad.hip); one tile per wave: the factor stores
 // need the registers the second tile would take
 int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out) {
   const int nkt = (a.geom.fin + 15) / 16;
   switch (nkt) {
-    case 14: return launch_t<14, 1, true>(a, stream, grid_out);
-    case 13: return launch_t<13, 1, true>(a, stream, grid_out);
-    case 8: return launch_t<8, 1, true>(a, stream, grid_out);
-    case 7: return launch_t<7, 1, true>(a, stream, grid_out);
+    case 14: return launch_t<14, 1, 1>(a, stream, grid_out);
+    case 13: return launch_t<13, 1, 1>(a, stream, grid_out);
+    case 8: return launch_t<8, 1, 1>(a, stream, grid_out);
+    case 7: return launch_t<7, 1, 1>(a, stream, grid_out);
     default:
       set_error("unsupported ONF feature dimension %d", a.geom.fin);
       return NFOPP_ERR_ARG;
@@ -628,6 +655,19 @@ extern "C" int nfopp_onf_eval_points(const nfopp_onf_config* cfg, const float* p
   a.n_points = n_points;
   a.out4 = out4_dev;
   return launch_onf_kernel(a, (hipStream_t)stream);
+}
+
+extern "C" int nfopp_onf_eval_logits(const nfopp_onf_config* cfg, const float* params_dev, const float* points_dev,
+                                     int64_t n_points, float* out4_dev, void* stream) {
+  OnfKernelArgs a = {};
+  NFOPP_REQUIRE(make_geom(cfg, &a.geom), "bad ONF configuration");
+  NFOPP_REQUIRE(n_points >= 0, "negative point count");
+  NFOPP_REQUIRE(n_points == 0 || (params_dev && points_dev && out4_dev), "null device pointer");
+  a.params = params_dev;
+  a.points = points_dev;
+  a.n_points = n_points;
+  a.out4 = out4_dev;
+  return launch_onf_logits_kernel(a, (hipStream_t)stream);
 }
 
 extern "C" int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const float* params_dev, const float* traj_dev,

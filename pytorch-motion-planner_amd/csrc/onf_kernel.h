@@ -35,6 +35,7 @@ struct OnfKernelArgs {
 };
 
 int launch_onf_kernel(const OnfKernelArgs& a, hipStream_t stream);
+int launch_onf_logits_kernel(const OnfKernelArgs& a, hipStream_t stream);
 int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);
 int onf_train_grid_upper_bound();
 

@@ -38,30 +38,30 @@ struct WgLayout {
 };
 
 struct WgradArgs {
-  const float* ws_in; const float* ws_h1; const float* ws_h2; const float* ws_dh1; const float* ws_dh2;
-  const float* ws_de; const float* ws_u;
+  // factor matrices, stored back to back in this order (carve_wgrad):  in [P,WIN] | h1 | h2 | dh1 | dh2 [P,112 each] |
+  // de [P,WIN] | u [P,4]  -- so every array starts at P * (compile-time floats-per-sample prefix)
+  const float* ws;
   long long P;
   float* partial;  // [grid][NTILES][256]
 };
 
-// column (within the combined LDS row) and source pointer of float4 number c of a sample
+// float4 number c (0 .. F4_PER_SAMPLE) of a sample: workspace offset of its source and its column in the combined LDS
+// row.  Branch-free selects over compile-time constants, because the lanes of a wave straddle the segment boundaries.
 template <int NKT>
-__device__ __forceinline__ void f4_source(const WgradArgs& a, long long p, int c, const float** src, int* col) {
+__device__ __forceinline__ void f4_source(long long P, long long p, int c, long long* src_off, int* col) {
   using W = WgLayout<NKT>;
   constexpr int h4 = HS / 4, w4 = W::WIN / 4;
-  if (c < h4) { *src = a.ws_dh1 + p * HS + 4 * c; *col = W::C_DH1 + 4 * c; return; }
-  c -= h4;
-  if (c < w4) { *src = a.ws_in + p * W::WIN + 4 * c; *col = W::C_IN + 4 * c; return; }
-  c -= w4;
-  if (c < h4) { *src = a.ws_dh2 + p * HS + 4 * c; *col = W::C_DH2 + 4 * c; return; }
-  c -= h4;
-  if (c < h4) { *src = a.ws_h1 + p * HS + 4 * c; *col = W::C_H1 + 4 * c; return; }
-  c -= h4;
-  if (c < w4) { *src = a.ws_de + p * W::WIN + 4 * c; *col = W::C_DE + 4 * c; return; }
-  c -= w4;
-  if (c < 1) { *src = a.ws_u + p * 4; *col = W::C_U; return; }
-  c -= 1;
-  *src = a.ws_h2 + p * HS + 4 * c; *col = W::C_H2 + 4 * c;
+  constexpr int t1 = h4, t2 = t1 + w4, t3 = t2 + h4, t4 = t3 + h4, t5 = t4 + w4, t6 = t5 + 1;
+  // (prefix = floats per sample stored before this array, row length, first c, LDS column)
+  int prefix = W::WIN + 2 * HS, row = HS, start = 0, lcol = W::C_DH1;                       // dh1
+  if (c >= t1) { prefix = 0; row = W::WIN; start = t1; lcol = W::C_IN; }                     // in
+  if (c >= t2) { prefix = W::WIN + 3 * HS; row = HS; start = t2; lcol = W::C_DH2; }          // dh2
+  if (c >= t3) { prefix = W::WIN; row = HS; start = t3; lcol = W::C_H1; }                    // h1
+  if (c >= t4) { prefix = W::WIN + 4 * HS; row = W::WIN; start = t4; lcol = W::C_DE; }       // de
+  if (c >= t5) { prefix = 2 * W::WIN + 4 * HS; row = 4; start = t5; lcol = W::C_U; }         // u
+  if (c >= t6) { prefix = W::WIN + HS; row = HS; start = t6; lcol = W::C_H2; }               // h2
+  *src_off = P * prefix + p * row + 4 * (c - start);
+  *col = lcol + 4 * (c - start);
 }
 
 template <int NKT>
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
         const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
         const long long p = chunk * KC + q;
         if (p < a.P) {
-          const float* src; int col;
-          f4_source<NKT>(a, p, c, &src, &col);
-          v = *reinterpret_cast<const f32x4*>(src);
+          long long src; int col;
+          f4_source<NKT>(a.P, p, c, &src, &col);
+          v = *reinterpret_cast<const f32x4*>(a.ws + src);
         }
       }
       stage[k] = v;
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
       const int idx = tid + k * WG_THREADS;
       if (idx < KC * W::F4_PER_SAMPLE) {
         const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
-        const float* src; int col;
-        f4_source<NKT>(a, 0, c, &src, &col);
+        long long src; int col;
+        f4_source<NKT>(0, 0, c, &src, &col);
         *reinterpret_cast<f32x4*>(lds + q * W::STRIDE + col) = stage[k];
       }
     }
@@ -326,8 +326,7 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
   if (rc) return rc;
 
   WgradArgs wa;
-  wa.ws_in = a.ws_in; wa.ws_h1 = a.ws_h1; wa.ws_h2 = a.ws_h2; wa.ws_dh1 = a.ws_dh1; wa.ws_dh2 = a.ws_dh2;
-  wa.ws_de = a.ws_de; wa.ws_u = a.ws_u; wa.P = P; wa.partial = ws + w.partial;
+  wa.ws = ws + w.in; wa.P = P; wa.partial = ws + w.partial;   // arrays back to back from w.in (see carve_wgrad)
   long long n_chunks = (P + KC - 1) / KC;
   int grid = (int)(n_chunks < w.grid_cap ? n_chunks : w.grid_cap);
   switch (nkt) {

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "nfopp_device_count": (ctypes.c_int, []),
     "nfopp_onf_param_count": (ctypes.c_int64, [ctypes.POINTER(OnfConfigC)]),
     "nfopp_onf_eval_points": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, ctypes.c_int64, _P, _P]),
+    "nfopp_onf_eval_logits": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, ctypes.c_int64, _P, _P]),
     "nfopp_traj_collision_eval": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, ctypes.c_int64, ctypes.c_int32,
                                                  ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                                  ctypes.c_int64, _P, _P]),

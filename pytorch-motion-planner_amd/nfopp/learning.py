@@ -106,7 +106,7 @@ class BatchSampler(object):
                                                _lib.stream_ptr()))
         if self.cap:
             cfg = self.onf.config_c()   # weights of the pool candidates: sigmoid(ONF) * exp(-0.03 age)  (nerf:124-126)
-            _lib.check(lib.nfopp_onf_eval_points(cfg, _lib.ptr(self.onf.flat_parameters), _lib.ptr(self.cand),
+            _lib.check(lib.nfopp_onf_eval_logits(cfg, _lib.ptr(self.onf.flat_parameters), _lib.ptr(self.cand),
                                                  self.B * self.C, _lib.ptr(self.cand_out), _lib.stream_ptr()))
             _lib.check(lib.nfopp_resample_pool(self.B, n_cand, self.C, self.cap, self.D, self.S, self.N - 1, self.seed, self.offset,
                                                self.traj_index_offset, _lib.ptr(self.cand), _lib.ptr(self.cand_age),

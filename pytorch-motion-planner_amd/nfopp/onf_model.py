@@ -108,8 +108,7 @@ class ONF(nn.Module):
         return _lib.OnfConfigC(self._mean, self._sigma, int(self._use_cos), int(self._bias), self._angle_dim)
 
     # ---- evaluation (HIP only) ------------------------------------------------------------------------------------
-    def forward_with_grad(self, x):
-        """x [P, point_dim] on the HIP device -> out4 [P, 4] = logit, dlogit/dx, dlogit/dy, dlogit/dtheta."""
+    def _eval(self, x, with_grad):
         _lib.require_gpu()
         if not self._flat.is_cuda:
             raise _lib.NfoppError("ONF parameters live on %s; move the model to the HIP device first" % self._flat.device)
@@ -118,11 +117,15 @@ class ONF(nn.Module):
             raise ValueError("expected points of shape [P, %d], got %s" % (self.point_dim, tuple(x.shape)))
         out = torch.empty(x.shape[0], 4, dtype=torch.float32, device=x.device)
         if x.shape[0]:
-            cfg = self.config_c()
-            _lib.check(_lib.load().nfopp_onf_eval_points(cfg, _lib.ptr(self._flat), _lib.ptr(x), x.shape[0],
-                                                         _lib.ptr(out), _lib.stream_ptr()))
+            lib = _lib.load()
+            fn = lib.nfopp_onf_eval_points if with_grad else lib.nfopp_onf_eval_logits
+            _lib.check(fn(self.config_c(), _lib.ptr(self._flat), _lib.ptr(x), x.shape[0], _lib.ptr(out), _lib.stream_ptr()))
         return out
 
+    def forward_with_grad(self, x):
+        """x [P, point_dim] on the HIP device -> out4 [P, 4] = logit, dlogit/dx, dlogit/dy, dlogit/dtheta."""
+        return self._eval(x, True)
+
     def forward(self, x):
-        """Logits [P, 1] like the reference module (nfop/onf_model.py:33-50)."""
-        return self.forward_with_grad(x)[:, :1]
+        """Logits [P, 1] like the reference module (nfop/onf_model.py:33-50); forward-only kernel."""
+        return self._eval(x, False)[:, :1]

@@ -314,3 +314,16 @@ def test_onf_training_mfma_path_vs_oracle_large(tag, P):
     # bitwise reproducible
     g_again = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 0)
     assert np.array_equal(g_auto, g_again)
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_forward_only_kernel_matches_the_full_kernel(tag):
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z[tag + "_cfg"], z[tag + "_params"])
+    for n in (3, 1024, 70001):
+        x = torch.tensor(np.resize(z[tag + "_x"], (n, z[tag + "_x"].shape[1])), device="cuda")
+        full = onf.forward_with_grad(x)
+        fwd = onf(x)
+        assert fwd.shape == (n, 1)
+        assert torch.equal(fwd[:, 0], full[:, 0])          # same arithmetic, bit for bit
+    assert gc.scaled_err(onf(torch.tensor(z[tag + "_x"], device="cuda")).cpu().numpy()[:, 0], z[tag + "_logit"]) < 1e-5
