@@ -190,3 +190,12 @@ def test_linspace_matches_torch():
     import torch
     for a, b, n in ((0.0, 1.0, 102), (0.5, 2.5, 258), (-3.0, 2.9, 52), (0.0, 1.0, 514)):
         assert np.array_equal(orc.linspace_f32(a, b, n), torch.linspace(a, b, n).numpy())
+
+
+
+# Note on the one known answer printed in the reference's files (notebooks/pytorch-optimal-planner.ipynb cell 8:
+# 0.0728476345539093): that prototype starts Adam from gradients that are exactly zero up to rounding noise (1e-9), and
+# Adam's first step turns rounding noise into +-lr moves, so the value is only reproducible with bit-identical op
+# order (torch 2.10 here: 0.07284770; this oracle's arithmetic: 0.0719).  It also uses an earlier form of the
+# non-holonomic term (start angle instead of the mean angle).  It therefore cannot pin a restatement; the fixtures
+# generated from the shipped planner classes (tests/golden/make_golden.py) do.
