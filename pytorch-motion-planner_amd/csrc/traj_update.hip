@@ -240,11 +240,25 @@ __global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdat
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     const int k0 = max(0, W - w), k1 = min(2 * W, N - 1 - w + W);
-    for (int k = k0; k <= k1; ++k) {
-      const float hv = a.hinv_band[(long long)k * N + w];
-      const int j = w + k - W;
+    const float* hb = a.hinv_band + w;
+    const float* gj = G + (w - W) * D;
+    int k = k0;
+    // whole-wave interior case (the common one): full band, 4 taps in flight per trip
+    if (__all(k0 == 0 && k1 == 2 * W)) {
+      for (; k + 3 <= k1; k += 4) {
+        float hv[4];
 #pragma unroll
-      for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, G[j * D + d], acc[d]);
+        for (int u = 0; u < 4; ++u) hv[u] = hb[(long long)(k + u) * N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int d = 0; d < D; ++d) acc[d] = fmaf(hv[u], gj[(k + u) * D + d], acc[d]);
+      }
+    }
+    for (; k <= k1; ++k) {
+      const float hv = hb[(long long)k * N];
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
