@@ -141,10 +141,17 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; the modulo only matters for a rehearsal of the N-rank flow on a box with fewer GPUs
+    # (NFOPP_DIST_BACKEND=gloo, several ranks sharing a card) -- on the benchmark node it is the identity
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = os.environ.get("NFOPP_DIST_BACKEND", "nccl")
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
 
     B, N = args.batch_per_gpu, N_WAYPOINTS
     obstacles, radius = make_environment()
@@ -190,7 +197,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

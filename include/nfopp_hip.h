@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NFOPP_ABI_VERSION 1
+#define NFOPP_ABI_VERSION 2
 #define NFOPP_HIDDEN 100 /* width of both hidden layers, nfop/onf_model.py:18-23 */
 
 typedef enum nfopp_status {
@@ -106,18 +106,19 @@ int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const float* params_d
  *   adam_m_dev/adam_v_dev [B,N,D], t_dev [B,N-1], onf_out4_dev [B,N-1,4]
  *   hinv_band_dev [2*half_width+1, N]: band of the reference's fp32 inverse Hessian (nerf:45-48), transposed so
  *       that entry [k][i] = Hinv[i][i + k - half_width] (0 outside the matrix)
- *   terms_dev [B, 8] or NULL: total, distance, sum softplus, sum lam*c, sum c^2, boundary, sum cm*tanh, sum relu(d)^2 */
+ *   terms_dev [B, 8] or NULL: total, distance, sum softplus, sum lam*c, sum c^2, boundary, sum cm*tanh, sum relu(d)^2
+ *   active_dev [B] uint8 or NULL: trajectories with 0 are left untouched (early stop, see nfopp_path_select_best) */
 int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int32_t n_waypoints, int32_t dim,
                       float* traj_dev, const float* start_dev, const float* goal_dev, float* lam_dev,
                       float* cm_dev, float* adam_m_dev, float* adam_v_dev, const float* t_dev,
                       const float* onf_out4_dev, const float* hinv_band_dev, int32_t half_width,
-                      float* terms_dev, void* stream);
+                      float* terms_dev, const uint8_t* active_dev, void* stream);
 
 /* Arc-length reparametrisation (constrained:132-171 for D = 3 incl. multipliers; nerf:224-244 for D = 2).
  *   u_dev [N] = torch.linspace(0, 1, N+2)[1:-1] (formed by the caller so its rounding is the reference's) */
 int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t dim, float* traj_dev,
                         const float* start_dev, const float* goal_dev, float* lam_dev, float* cm_dev,
-                        const float* u_dev, void* stream);
+                        const float* u_dev, const uint8_t* active_dev, void* stream);
 
 /* ONF fitting step, gradient part: BCE-with-logits (mean over ALL samples of the job) and its gradient w.r.t.
  * every parameter incl. the angle frequencies (nfop/nerf_opt_planner.py:83-89).
@@ -175,6 +176,19 @@ int nfopp_resample_pool(int64_t batch, int32_t n_candidates, int32_t cand_stride
                         const float* cand_dev, const float* cand_age_dev, const float* onf_out4_dev, float* pool_dev,
                         float* pool_age_dev, float* samples_dev, void* stream);
 
+/* ---- path evaluation (the step after the planner step: scripts/run_bench_mr.py:109-132) ---------------------------
+ * nfopp_path_interpolate: densifies start -> waypoints -> goal with `sub` poses per segment (theta along the wrapped
+ *   difference) into poses_dev [B, (N+1)*sub + 1, D] and writes the xy polyline length to length_dev [B].
+ * The caller labels the poses with a ground-truth checker (above), then
+ * nfopp_path_select_best: collides[b] = any label set; a collision-free path shorter than best_length[b] replaces
+ *   best_traj[b]; a collision-free path that does not improve clears active[b] (the reference's `break`); inactive
+ *   trajectories are skipped by nfopp_traj_update / nfopp_reparametrize when active_dev is passed to them. */
+int nfopp_path_interpolate(const float* traj_dev, const float* start_dev, const float* goal_dev, int64_t batch,
+                           int32_t n_waypoints, int32_t dim, int32_t sub, float* poses_dev, float* length_dev,
+                           void* stream);
+int nfopp_path_select_best(const float* labels_dev, const float* length_dev, const float* traj_dev, int64_t batch,
+                           int32_t poses_per_path, int32_t n_waypoints, int32_t dim, float* best_traj_dev,
+                           float* best_length_dev, uint8_t* collides_dev, uint8_t* active_dev, void* stream);
 /* torch.optim.Adam single-tensor update on a flat buffer (used for the ONF weights after the gradient
  * all-reduce): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps). */
 int nfopp_adam_step(float* param_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, float beta2,

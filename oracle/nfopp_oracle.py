@@ -600,3 +600,33 @@ def grid_check(xy, grid, origin_x, origin_y, cell):
     out = np.ones(len(xy), bool)
     out[inside] = grid[iy[inside], ix[inside]] > 0
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# path evaluation (csrc/path_eval.hip; loop of scripts/run_bench_mr.py:109-132 with generic densification)
+def path_interpolate(traj, start, goal, sub):
+    """-> (poses [B, (N+1)*sub + 1, D], xy polyline length [B])."""
+    q = full_trajectory(np.asarray(traj, F32), np.asarray(start, F32), np.asarray(goal, F32))
+    B, n2, D = q.shape
+    p0, p1 = q[:, :-1], q[:, 1:]
+    delta = (p1 - p0).astype(F32)
+    if D == 3:
+        delta[..., 2] = wrap_angle(delta[..., 2])
+    u = (np.arange(sub, dtype=F32) / F32(sub))[None, None, :, None]
+    poses = (p0[:, :, None, :] + u * delta[:, :, None, :]).astype(F32).reshape(B, (n2 - 1) * sub, D)
+    poses = np.concatenate([poses, q[:, -1:]], 1)
+    seg = q[:, 1:, :2] - q[:, :-1, :2]
+    length = np.sqrt(np.sum(seg * seg, 2, dtype=F32)).astype(F32).sum(1, dtype=F32)
+    return poses, length
+
+
+def path_select_best(labels, length, traj, best_traj, best_length, active=None):
+    """Best-path bookkeeping + early stop.  Returns (collides, best_traj, best_length, active)."""
+    labels = np.asarray(labels)
+    collides = (labels != 0).any(1)
+    was_active = np.ones(len(length), bool) if active is None else np.asarray(active, bool)
+    improve = was_active & ~collides & (length < best_length)
+    best_traj = np.where(improve[:, None, None], traj, best_traj)
+    best_length = np.where(improve, length, best_length)
+    new_active = None if active is None else was_active & ~(~collides & ~improve)
+    return collides, best_traj, best_length, new_active

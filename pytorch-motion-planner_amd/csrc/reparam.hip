@@ -19,6 +19,7 @@ struct ReparamArgs {
   float* lam;
   float* cm;
   const float* u;
+  const unsigned char* active;
 };
 
 template <int D>
@@ -26,6 +27,7 @@ __global__ __launch_bounds__(RP_THREADS) void reparam_kernel(const ReparamArgs a
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = a.n, tid = threadIdx.x;
   const long long b = blockIdx.x;
+  if (a.active && !a.active[b]) return;  // retired trajectory
   float* Q = sm;                  // (N+2)*D
   float* cdf = Q + (N + 2) * D;   // N+2
   float* cmf = cdf + (N + 2);     // N+2   [0, cm, 0]
@@ -110,7 +112,7 @@ using namespace nfopp;
 
 extern "C" int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t dim, float* traj_dev,
                                    const float* start_dev, const float* goal_dev, float* lam_dev, float* cm_dev,
-                                   const float* u_dev, void* stream) {
+                                   const float* u_dev, const uint8_t* active_dev, void* stream) {
   NFOPP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
   NFOPP_REQUIRE(batch <= 0x7fffffffLL, "batch too large for one launch");
@@ -119,7 +121,7 @@ extern "C" int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t d
   NFOPP_REQUIRE(dim == 2 || (lam_dev && cm_dev), "SE(2) reparametrisation needs the multiplier arrays");
   ReparamArgs a;
   a.n = n_waypoints; a.dim = dim; a.traj = traj_dev; a.start = start_dev; a.goal = goal_dev;
-  a.lam = lam_dev; a.cm = cm_dev; a.u = u_dev;
+  a.lam = lam_dev; a.cm = cm_dev; a.u = u_dev; a.active = active_dev;
   const size_t lds = (size_t)((n_waypoints + 2) * dim + 3 * (n_waypoints + 2) + n_waypoints + RP_THREADS / 64) * 4;
   NFOPP_REQUIRE(lds <= 160 * 1024, "trajectory too long for one workgroup's LDS (%zu bytes)", lds);
   auto kern = dim == 3 ? reparam_kernel<3> : reparam_kernel<2>;

@@ -30,6 +30,7 @@ struct TrajUpdateArgs {
   const float* hinv_band;
   int half_width;
   float* terms;
+  const unsigned char* active;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdat
   float* CM = LAM + (N + 1);        // N collision multipliers
   float* scratch = CM + N;          // block reductions
   const long long b = blockIdx.x;
+  if (a.active && !a.active[b]) return;  // retired trajectory (uniform per workgroup)
   const nfopp_traj_hyper& hp = a.hp;
   const int tid = threadIdx.x;
 
@@ -296,7 +298,7 @@ extern "C" int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int3
                                  float* traj_dev, const float* start_dev, const float* goal_dev, float* lam_dev,
                                  float* cm_dev, float* adam_m_dev, float* adam_v_dev, const float* t_dev,
                                  const float* onf_out4_dev, const float* hinv_band_dev, int32_t half_width,
-                                 float* terms_dev, void* stream) {
+                                 float* terms_dev, const uint8_t* active_dev, void* stream) {
   NFOPP_REQUIRE(hp, "null hyper-parameter block");
   NFOPP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
@@ -311,7 +313,7 @@ extern "C" int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int3
   a.batch = batch; a.n = n_waypoints; a.dim = dim;
   a.traj = traj_dev; a.start = start_dev; a.goal = goal_dev; a.lam = lam_dev; a.cm = cm_dev;
   a.adam_m = adam_m_dev; a.adam_v = adam_v_dev; a.t = t_dev; a.onf = onf_out4_dev;
-  a.hinv_band = hinv_band_dev; a.half_width = half_width; a.terms = terms_dev;
+  a.hinv_band = hinv_band_dev; a.half_width = half_width; a.terms = terms_dev; a.active = active_dev;
   const size_t lds = (size_t)((n_waypoints + 2) * dim + n_waypoints * dim + 2 * n_waypoints + 1 +
                               NFOPP_NUM_TERMS * (TU_THREADS / 64)) * 4;
   NFOPP_REQUIRE(lds <= 160 * 1024, "trajectory too long for one workgroup's LDS (%zu bytes)", lds);

@@ -86,7 +86,8 @@ class OnfFitter(object):
     def global_count(self, local_count):
         if self.group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             return int(local_count)
-        c = torch.tensor([float(local_count)], dtype=torch.float64, device=self.grad.device)
+        gloo = torch.distributed.get_backend(self.group) == "gloo"
+        c = torch.tensor([float(local_count)], dtype=torch.float64, device="cpu" if gloo else self.grad.device)
         torch.distributed.all_reduce(c, group=self.group)
         return int(c.item())
 
@@ -96,7 +97,12 @@ class OnfFitter(object):
         total = self.global_count(p) if global_count is None else int(global_count)
         self._grad_fn(samples, labels, 1.0 / total)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.all_reduce(self.grad, group=self.group)   # SUM; RCCL on the "nccl" backend
+            if self.grad.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+                host = self.grad.cpu()           # rehearsal path only: gloo reduces host buffers
+                torch.distributed.all_reduce(host, group=self.group)
+                self.grad.copy_(host)
+            else:
+                torch.distributed.all_reduce(self.grad, group=self.group)   # SUM; RCCL on the "nccl" backend
         self.step_count += 1
         b1, b2 = self.betas
         step_size = self.lr / (1 - b1 ** self.step_count)
@@ -168,3 +174,46 @@ class BatchPlanner(object):
 
     def get_paths(self):
         return self.engine.full_trajectory().detach().cpu().numpy()
+
+    # ---- path evaluation, best-path bookkeeping, early stop (scripts/run_bench_mr.py:109-132 for the batch) ---------
+    def evaluate(self, checker=None, sub=4, early_stop=False):
+        """Densifies every path (`sub` poses per segment), labels the poses with the ground-truth `checker`, keeps
+        the shortest collision-free path per trajectory and -- with early_stop -- retires trajectories that are
+        collision-free but no longer improving.  Returns device tensors (collides uint8 [B], length [B])."""
+        from . import _lib as L
+        checker = checker or self.checker
+        if checker is None:
+            raise ValueError("evaluate() needs a ground-truth checker")
+        eng = self.engine
+        B, N, D = eng.B, eng.N, eng.D
+        m = (N + 1) * int(sub) + 1
+        f32 = dict(dtype=torch.float32, device=eng.device)
+        if getattr(self, "_eval_sub", None) != sub:
+            self._eval_sub = sub
+            self._poses = torch.empty(B, m, D, **f32)
+            self._pose_labels = torch.empty(B * m, **f32)
+            self._length = torch.empty(B, **f32)
+            self._collides = torch.zeros(B, dtype=torch.uint8, device=eng.device)
+        if not hasattr(self, "best_length"):
+            self.best_length = torch.full((B,), float("inf"), **f32)
+            self.best_traj = eng.traj.detach().clone().view(B, N, D)
+        if early_stop and eng.active is None:
+            eng.active = torch.ones(B, dtype=torch.uint8, device=eng.device)
+        lib = L.load()
+        L.check(lib.nfopp_path_interpolate(L.ptr(eng.traj), L.ptr(eng.start), L.ptr(eng.goal), B, N, D, int(sub),
+                                           L.ptr(self._poses), L.ptr(self._length), L.stream_ptr()))
+        checker.labels(self._poses.view(B * m, D), out=self._pose_labels)
+        L.check(lib.nfopp_path_select_best(L.ptr(self._pose_labels), L.ptr(self._length), L.ptr(eng.traj), B, m, N, D,
+                                           L.ptr(self.best_traj), L.ptr(self.best_length),
+                                           L.ptr(self._collides, torch.uint8),
+                                           L.ptr(eng.active, torch.uint8) if early_stop else None, L.stream_ptr()))
+        return self._collides, self._length
+
+    def best_paths(self):
+        """[B, N+2, D]: the best collision-free path found so far, the current path where none was found yet."""
+        eng = self.engine
+        if not hasattr(self, "best_length"):
+            return self.get_paths()
+        found = torch.isfinite(self.best_length)[:, None, None]
+        tr = torch.where(found, self.best_traj, eng.traj.view(eng.B, eng.N, eng.D))
+        return torch.cat([eng.start[:, None], tr, eng.goal[:, None]], dim=1).cpu().numpy()

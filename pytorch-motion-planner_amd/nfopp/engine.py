@@ -123,6 +123,7 @@ class TrajectoryEngine(object):
         self.hinv_band = torch.tensor(band, **f32)
         self.u = torch.linspace(0, 1, N + 2)[1:-1].contiguous().to(self.device)  # CPU linspace: reference rounding
         self.seed, self.rng_offset, self.traj_index_offset = int(seed), 0, int(traj_index_offset)
+        self.active = None   # optional uint8 [B] mask: 0 = retired trajectory (early stop), left untouched by update/reparam
         self._check_traj()
 
     def _check_traj(self):
@@ -156,7 +157,8 @@ class TrajectoryEngine(object):
                                          _lib.ptr(self.goal), _lib.ptr(self.lam), _lib.ptr(self.cm),
                                          _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.ptr(self.t),
                                          _lib.ptr(self.onf_out), _lib.ptr(self.hinv_band), self.half_width,
-                                         _lib.ptr(self.terms) if want_terms else None, _lib.stream_ptr()))
+                                         _lib.ptr(self.terms) if want_terms else None,
+                                         _lib.ptr(self.active, torch.uint8), _lib.stream_ptr()))
 
     def optimize_trajectory(self, t=None, want_terms=True):
         """One `_optimize_trajectory` (nfop/nerf_opt_planner.py:143-155 + constrained:63-74) for the whole batch."""
@@ -167,7 +169,7 @@ class TrajectoryEngine(object):
         lib = _lib.load()
         _lib.check(lib.nfopp_reparametrize(self.B, self.N, self.D, _lib.ptr(self.traj), _lib.ptr(self.start),
                                            _lib.ptr(self.goal), _lib.ptr(self.lam), _lib.ptr(self.cm),
-                                           _lib.ptr(self.u), _lib.stream_ptr()))
+                                           _lib.ptr(self.u), _lib.ptr(self.active, torch.uint8), _lib.stream_ptr()))
 
     # ---- helpers --------------------------------------------------------------------------------------------------
     def set_endpoints(self, start, goal):

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from .engine import TrajectoryEngine, TrajectoryHyper
-from .host_utils import Position2, wrap_angle_np
+from .host_utils import Position2
 
 
 class ContinuousPlanner(object):

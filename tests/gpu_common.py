@@ -54,18 +54,5 @@ def scaled_err(a, b):
 
 
 def philox_uniform_np(seed, ctr_lo, ctr_hi):
-    """numpy restatement of csrc/common.h philox_uniform (Philox4x32-10, word 0 -> 24-bit uniform)."""
-    ctr_lo = np.asarray(ctr_lo, np.uint64)
-    c0 = (ctr_lo & np.uint64(0xFFFFFFFF)).astype(np.uint64)
-    c1 = (ctr_lo >> np.uint64(32)).astype(np.uint64)
-    c2 = np.full_like(c0, np.uint64(ctr_hi & 0xFFFFFFFF))
-    c3 = np.full_like(c0, np.uint64((ctr_hi >> 32) & 0xFFFFFFFF))
-    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
-    for _ in range(10):
-        p0, p1 = M0 * c0, M1 * c2
-        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
-        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
-        k0 = (k0 + np.uint64(0x9E3779B9)) & MASK
-        k1 = (k1 + np.uint64(0xBB67AE85)) & MASK
-    return ((c0 >> np.uint64(8)).astype(np.float64) * 2.0 ** -24).astype(F32)
+    """Philox4x32-10 word 0 -> 24-bit uniform: the oracle's restatement of csrc/common.h philox_uniform."""
+    return orc.philox_uniform(seed, np.asarray(ctr_lo, np.uint64), ctr_hi)

@@ -94,3 +94,45 @@ def test_batch_planner_learns_the_field_while_planning():
     probe = torch.tensor([[1.5, 1.5, 0.0], [0.5, 1.5, 0.0], [2.5, 0.4, 0.0]], device="cuda")
     logit = onf(probe).cpu().numpy()[:, 0]
     assert logit[0] > 0 > logit[1] and logit[2] < 0
+
+
+@pytest.mark.parametrize("D", [3, 2])
+def test_path_evaluation_and_early_stop_vs_oracle(D):
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z["a_cfg" if D == 3 else "c_cfg"], z["a_params" if D == 3 else "c_params"])
+    rng = np.random.default_rng(7 + D)
+    B, N, sub = 9, 33, 5
+    obstacles = np.array([[1.5, y] for y in np.linspace(0.0, 1.6, 9)])
+    checker = nfopp.DeviceCircleChecker(obstacles, 0.25, (0, 3, 0, 3))
+    starts = np.concatenate([rng.uniform(0.2, 0.6, (B, 1)), rng.uniform(0.3, 2.7, (B, 1)), rng.uniform(-3, 3, (B, 1))], 1)[:, :D].astype(F32)
+    goals = np.concatenate([rng.uniform(2.4, 2.8, (B, 1)), rng.uniform(0.3, 2.7, (B, 1)), rng.uniform(-3, 3, (B, 1))], 1)[:, :D].astype(F32)
+    hyper = nfopp.TrajectoryHyper(bounds=(0, 3, 0, 3)) if D == 3 else nfopp.TrajectoryHyper(collision_weight=0.01, bounds=(0, 3, 0, 3))
+    planner = nfopp.BatchPlanner(onf, B, N, hyper)
+    planner.init(starts, goals, (0, 3, 0, 3))
+    eng = planner.engine
+    traj0 = eng.traj.cpu().numpy().reshape(B, N, D)
+    collides, length = planner.evaluate(checker, sub=sub, early_stop=True)
+    torch.cuda.synchronize()
+    poses, ref_len = orc.path_interpolate(traj0, starts, goals, sub)
+    assert max_abs(planner._poses.cpu().numpy(), poses) < 1e-6
+    assert max_abs(length.cpu().numpy(), ref_len) < 1e-5
+    labels = orc.circle_check(poses.reshape(-1, D)[:, :2].astype(np.float64), obstacles, 0.25, (0, 3, 0, 3)).reshape(B, -1)
+    ref_col, ref_best, ref_bl, ref_act = orc.path_select_best(labels, ref_len, traj0, traj0.copy(), np.full(B, np.inf, F32),
+                                                              np.ones(B, bool))
+    assert np.array_equal(collides.cpu().numpy().astype(bool), ref_col)
+    assert 0 < ref_col.sum() < B                                   # straight lines: some cross the wall, some do not
+    assert np.array_equal(np.isfinite(planner.best_length.cpu().numpy()), ~ref_col)
+    assert eng.active.cpu().numpy().all()                          # first evaluation never retires (everything improves)
+    # second evaluation of the SAME paths: collision-free ones do not improve -> retired; colliding ones stay active
+    planner.evaluate(checker, sub=sub, early_stop=True)
+    act = eng.active.cpu().numpy().astype(bool)
+    assert np.array_equal(act, ref_col)
+    # retired trajectories are frozen by the step kernels, active ones keep moving
+    before = eng.traj.clone()
+    for _ in range(11):
+        planner.step()
+    moved = (eng.traj - before).abs().reshape(B, -1).amax(1).cpu().numpy() > 0
+    assert np.array_equal(moved, act)
+    best = planner.best_paths()
+    assert best.shape == (B, N + 2, D)
+    assert max_abs(best[~ref_col][:, 1:-1], traj0[~ref_col]) == 0

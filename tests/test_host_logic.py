@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_header_symbol():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nfopp_abi_version() == 1
+    assert lib.nfopp_abi_version() == 2
     assert lib.nfopp_device_count() >= 0
 
 
@@ -40,7 +40,7 @@ def test_param_count_and_argument_errors_without_gpu():
     # argument validation happens before any HIP call
     rc = lib.nfopp_onf_eval_points(_lib.OnfConfigC(0, 1, 1, 1, 10), None, None, 4, None, None)
     assert rc == -1 and b"null" in lib.nfopp_last_error()
-    rc = lib.nfopp_reparametrize(1, 10, 4, None, None, None, None, None, None, None)
+    rc = lib.nfopp_reparametrize(1, 10, 4, None, None, None, None, None, None, None, None)
     assert rc == -1
 
 
