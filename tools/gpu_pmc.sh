@@ -22,7 +22,7 @@ for name in ("fetch","write","sq1","sq2"):
     agg = collections.defaultdict(list)
     for f in files:
         for row in csv.DictReader(open(f)):
-            if "onf_fwd_bwd" in row.get("Kernel_Name",""):
+            if "onf_fwd_bwd_kernel<14, 2, 0>" in row.get("Kernel_Name",""):
                 agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k,v in agg.items():
         print(name, k, "n=%d mean=%.6g" % (len(v), sum(v)/len(v)))

@@ -16,7 +16,7 @@ for name in ("a","b"):
     agg = collections.defaultdict(list)
     for f in glob.glob("gpurun_out/pmc2/%s/**/*counter_collection.csv" % name, recursive=True):
         for row in csv.DictReader(open(f)):
-            if "onf_fwd_bwd" in row.get("Kernel_Name",""):
+            if "onf_fwd_bwd_kernel<14, 2, 0>" in row.get("Kernel_Name",""):
                 agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k,v in sorted(agg.items()):
         print(name, k, "n=%d mean=%.6g" % (len(v), sum(v)/len(v)))
