@@ -63,7 +63,7 @@ def make_onf(device, obstacles, radius, fit_iters, fit_points):
     """ONF of scripts/run_bench_mr.py:28-36 (sigma=10), fitted to the map with the HIP training kernel, then frozen."""
     torch.random.manual_seed(100)
     onf = nfopp.ONF(0, 10, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to(device)
-    fitter = nfopp.OnfFitter(onf, lr=2e-2, betas=(0.9, 0.9))
+    fitter = nfopp.OnfFitter(onf, lr=2e-2, betas=(0.9, 0.9), distributed=False)   # every rank fits the same field
     rng = np.random.default_rng(77)
     for _ in range(fit_iters):
         x = np.concatenate([rng.uniform(0, 100, (fit_points, 2)), rng.uniform(0, 2 * np.pi, (fit_points, 1))], 1)

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
           if (TRAIN) { acc[0][r] = de.x; acc[NT - 1][r] = de.y; }
           gx2 = fma2(de, wx, gx2);
           gy2 = fma2(de, wy, gy2);
-          gt2 = fma2(de, fr, gt2);
+          if (ANG) gt2 = fma2(de, fr, gt2);   // spatial features have no theta dependence (fr = 0)
         }
         gx[0] = gx2.x; gx[NT - 1] = gx2.y; gy[0] = gy2.x; gy[NT - 1] = gy2.y; gt[0] = gt2.x; gt[NT - 1] = gt2.y;
       } else {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
           if (TRAIN) { acc[0][r] = de.x; acc[0][r + 1] = de.y; }
           gx[0] = fmaf(de.x, wx.x, gx[0]); gx[0] = fmaf(de.y, wx.y, gx[0]);
           gy[0] = fmaf(de.x, wy.x, gy[0]); gy[0] = fmaf(de.y, wy.y, gy[0]);
-          gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]);
+          if (ANG) { gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]); }
         }
       }
       if (TRAIN) {

@@ -54,8 +54,10 @@ def straight_line_init(starts, goals, n_waypoints):
 class OnfFitter(object):
     """One BCE/Adam step of the shared field on this rank's samples; gradients summed over `group` first."""
 
-    def __init__(self, onf, lr, betas, eps=1e-8, group=None, grad_fn=None):
+    def __init__(self, onf, lr, betas, eps=1e-8, group=None, grad_fn=None, distributed=True):
         self.onf, self.lr, self.betas, self.eps, self.group = onf, float(lr), tuple(betas), float(eps), group
+        # distributed=False: purely local fit even inside an initialised process group (e.g. identical pre-fits)
+        self.distributed = bool(distributed)
         flat = onf.flat_parameters
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
@@ -83,8 +85,11 @@ class OnfFitter(object):
                                                _lib.ptr(self.v), self.onf.n_params, b2, 1 - b1, 1 - b2, self.eps,
                                                step_size, bc2_sqrt, _lib.stream_ptr()))
 
+    def _in_group(self):
+        return self.distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
+
     def global_count(self, local_count):
-        if self.group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if not self._in_group():
             return int(local_count)
         gloo = torch.distributed.get_backend(self.group) == "gloo"
         c = torch.tensor([float(local_count)], dtype=torch.float64, device="cpu" if gloo else self.grad.device)
@@ -96,7 +101,7 @@ class OnfFitter(object):
         p = samples.shape[0]
         total = self.global_count(p) if global_count is None else int(global_count)
         self._grad_fn(samples, labels, 1.0 / total)
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        if self._in_group():
             if self.grad.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
                 host = self.grad.cpu()           # rehearsal path only: gloo reduces host buffers
                 torch.distributed.all_reduce(host, group=self.group)
