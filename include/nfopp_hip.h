@@ -106,13 +106,17 @@ int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const float* params_d
  *   adam_m_dev/adam_v_dev [B,N,D], t_dev [B,N-1], onf_out4_dev [B,N-1,4]
  *   hinv_band_dev [2*half_width+1, N]: band of the reference's fp32 inverse Hessian (nerf:45-48), transposed so
  *       that entry [k][i] = Hinv[i][i + k - half_width] (0 outside the matrix)
+ *   interior_lo/hi: waypoints i in [lo, hi) whose band column equals column lo BIT FOR BIT (the inverse of a
+ *       tridiagonal Toeplitz matrix is Toeplitz away from the ends); their coefficients are broadcast from LDS.
+ *       Pass lo = hi = 0 to disable.
  *   terms_dev [B, 8] or NULL: total, distance, sum softplus, sum lam*c, sum c^2, boundary, sum cm*tanh, sum relu(d)^2
  *   active_dev [B] uint8 or NULL: trajectories with 0 are left untouched (early stop, see nfopp_path_select_best) */
 int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int32_t n_waypoints, int32_t dim,
                       float* traj_dev, const float* start_dev, const float* goal_dev, float* lam_dev,
                       float* cm_dev, float* adam_m_dev, float* adam_v_dev, const float* t_dev,
                       const float* onf_out4_dev, const float* hinv_band_dev, int32_t half_width,
-                      float* terms_dev, const uint8_t* active_dev, void* stream);
+                      int32_t interior_lo, int32_t interior_hi, float* terms_dev, const uint8_t* active_dev,
+                      void* stream);
 
 /* Arc-length reparametrisation (constrained:132-171 for D = 3 incl. multipliers; nerf:224-244 for D = 2).
  *   u_dev [N] = torch.linspace(0, 1, N+2)[1:-1] (formed by the caller so its rounding is the reference's) */

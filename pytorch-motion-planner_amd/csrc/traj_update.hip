@@ -29,6 +29,7 @@ struct TrajUpdateArgs {
   const float* onf;
   const float* hinv_band;
   int half_width;
+  int interior_lo, interior_hi;  // waypoints whose band column equals column interior_lo bit for bit (Toeplitz interior)
   float* terms;
   const unsigned char* active;
 };
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdat
   float* G = Q + (N + 2) * D;       // N * D gradient
   float* LAM = G + N * D;           // N+1 constraint multipliers (read-only copy: the update writes global)
   float* CM = LAM + (N + 1);        // N collision multipliers
-  float* scratch = CM + N;          // block reductions
+  float* COEF = CM + N;             // 2W+1 interior band coefficients
+  float* scratch = COEF + (2 * a.half_width + 1);  // block reductions
   const long long b = blockIdx.x;
   if (a.active && !a.active[b]) return;  // retired trajectory (uniform per workgroup)
   const nfopp_traj_hyper& hp = a.hp;
@@ -136,6 +138,8 @@ __global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdat
     for (int k = tid; k <= N; k += TU_THREADS) LAM[k] = a.lam[b * (N + 1) + k];
     for (int k = tid; k < N; k += TU_THREADS) CM[k] = a.cm[b * N + k];
   }
+  if (a.interior_hi > a.interior_lo)
+    for (int k = tid; k <= 2 * a.half_width; k += TU_THREADS) COEF[k] = a.hinv_band[(long long)k * N + a.interior_lo];
   __syncthreads();
 
   const float* tb = a.t + b * (N - 1);
@@ -244,28 +248,40 @@ __global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdat
     const int k0 = max(0, W - w), k1 = min(2 * W, N - 1 - w + W);
     const float* hb = a.hinv_band + w;
     const float* gj = G + (w - W) * D;
-    int k = k0;
-    // whole-wave interior case (the common one): full band, 4 taps in flight per trip
-    if (__all(k0 == 0 && k1 == 2 * W)) {
-      for (; k + 3 <= k1; k += 4) {
-        float hv[4];
+    // optimiser state is independent of the band product: issue its loads before the (latency-bound) taps
+    float m_in[D], v_in[D];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) hv[u] = hb[(long long)(k + u) * N];
+    for (int d = 0; d < D; ++d) { m_in[d] = am[w * D + d]; v_in[d] = av[w * D + d]; }
+    if (__all(w >= a.interior_lo && w < a.interior_hi)) {
+      // interior wave: every lane's band column is the SAME vector -> coefficients broadcast from LDS, no global loads
+      for (int k = 0; k <= 2 * W; ++k) {
+        const float hv = COEF[k];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int d = 0; d < D; ++d) acc[d] = fmaf(hv[u], gj[(k + u) * D + d], acc[d]);
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
       }
-    }
-    for (; k <= k1; ++k) {
-      const float hv = hb[(long long)k * N];
+    } else {
+      int k = k0;
+      if (__all(k0 == 0 && k1 == 2 * W)) {   // full band for the whole wave: 4 taps in flight per trip
+        for (; k + 3 <= k1; k += 4) {
+          float hv[4];
 #pragma unroll
-      for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
+          for (int u = 0; u < 4; ++u) hv[u] = hb[(long long)(k + u) * N];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(hv[u], gj[(k + u) * D + d], acc[d]);
+        }
+      }
+      for (; k <= k1; ++k) {
+        const float hv = hb[(long long)k * N];
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
+      }
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const float g = acc[d];
-      float m = am[w * D + d], v = av[w * D + d];
+      float m = m_in[d], v = v_in[d];
       m = m + hp.adam_omb1 * (g - m);
       v = v * hp.adam_beta2 + (hp.adam_omb2 * g) * g;
       const float denom = sqrtf(v) / hp.adam_bc2_sqrt + hp.adam_eps;
@@ -298,11 +314,13 @@ extern "C" int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int3
                                  float* traj_dev, const float* start_dev, const float* goal_dev, float* lam_dev,
                                  float* cm_dev, float* adam_m_dev, float* adam_v_dev, const float* t_dev,
                                  const float* onf_out4_dev, const float* hinv_band_dev, int32_t half_width,
-                                 float* terms_dev, const uint8_t* active_dev, void* stream) {
+                                 int32_t interior_lo, int32_t interior_hi, float* terms_dev,
+                                 const uint8_t* active_dev, void* stream) {
   NFOPP_REQUIRE(hp, "null hyper-parameter block");
   NFOPP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
   NFOPP_REQUIRE(half_width >= 0, "negative band half-width");
+  NFOPP_REQUIRE(interior_lo >= 0 && interior_hi <= n_waypoints, "interior range outside the trajectory");
   if (batch == 0) return NFOPP_OK;
   NFOPP_REQUIRE(traj_dev && start_dev && goal_dev && adam_m_dev && adam_v_dev && t_dev && onf_out4_dev &&
                     hinv_band_dev,
@@ -314,8 +332,9 @@ extern "C" int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int3
   a.traj = traj_dev; a.start = start_dev; a.goal = goal_dev; a.lam = lam_dev; a.cm = cm_dev;
   a.adam_m = adam_m_dev; a.adam_v = adam_v_dev; a.t = t_dev; a.onf = onf_out4_dev;
   a.hinv_band = hinv_band_dev; a.half_width = half_width; a.terms = terms_dev; a.active = active_dev;
+  a.interior_lo = interior_lo; a.interior_hi = interior_hi > interior_lo ? interior_hi : interior_lo;
   const size_t lds = (size_t)((n_waypoints + 2) * dim + n_waypoints * dim + 2 * n_waypoints + 1 +
-                              NFOPP_NUM_TERMS * (TU_THREADS / 64)) * 4;
+                              2 * half_width + 1 + NFOPP_NUM_TERMS * (TU_THREADS / 64)) * 4;
   NFOPP_REQUIRE(lds <= 160 * 1024, "trajectory too long for one workgroup's LDS (%zu bytes)", lds);
   NFOPP_REQUIRE(batch <= 0x7fffffffLL, "batch too large for one launch");
   auto kern = dim == 3 ? traj_update_kernel<3> : traj_update_kernel<2>;

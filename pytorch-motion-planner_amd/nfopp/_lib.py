@@ -46,7 +46,8 @@ _SIGNATURES = {
                                                  ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                                  ctypes.c_int64, _P, _P]),
     "nfopp_traj_update": (ctypes.c_int, [ctypes.POINTER(TrajHyperC), ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
-                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, _P, _P, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_int32, _P, _P, _P]),
     "nfopp_reparametrize": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nfopp_path_interpolate": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                               _P, _P, _P]),

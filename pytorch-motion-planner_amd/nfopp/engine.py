@@ -49,6 +49,21 @@ def band_of(hinv, rel_tol=1e-9):
     return band, w
 
 
+def interior_range(band):
+    """[lo, hi): the longest run of waypoints around the centre whose band column is bit-identical to the centre's
+    (the inverse of a tridiagonal Toeplitz matrix is Toeplitz away from the ends: the boundary terms decay like
+    r^(2*distance) and vanish below fp32 resolution).  The kernel broadcasts these coefficients from LDS."""
+    n = band.shape[1]
+    c = n // 2
+    same = np.all(band == band[:, c:c + 1], axis=0)
+    lo, hi = c, c + 1
+    while lo > 0 and same[lo - 1]:
+        lo -= 1
+    while hi < n and same[hi]:
+        hi += 1
+    return (lo, hi) if hi - lo >= 64 else (0, 0)
+
+
 class TrajectoryHyper(object):
     """Scalars of the trajectory step (nfop/constrained_nerf_opt_planner.py:13-40 + the Adam group)."""
 
@@ -120,6 +135,7 @@ class TrajectoryEngine(object):
         self.terms = torch.zeros(B, _lib.NUM_TERMS, **f32)
         self.hinv = inverse_hessian(N, velocity_hessian_weight)
         band, self.half_width = band_of(self.hinv)
+        self.interior = interior_range(band)
         self.hinv_band = torch.tensor(band, **f32)
         self.u = torch.linspace(0, 1, N + 2)[1:-1].contiguous().to(self.device)  # CPU linspace: reference rounding
         self.seed, self.rng_offset, self.traj_index_offset = int(seed), 0, int(traj_index_offset)
@@ -157,6 +173,7 @@ class TrajectoryEngine(object):
                                          _lib.ptr(self.goal), _lib.ptr(self.lam), _lib.ptr(self.cm),
                                          _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.ptr(self.t),
                                          _lib.ptr(self.onf_out), _lib.ptr(self.hinv_band), self.half_width,
+                                         self.interior[0], self.interior[1],
                                          _lib.ptr(self.terms) if want_terms else None,
                                          _lib.ptr(self.active, torch.uint8), _lib.stream_ptr()))
 
