@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NFOPP_ABI_VERSION 2
+#define NFOPP_ABI_VERSION 3
 #define NFOPP_HIDDEN 100 /* width of both hidden layers, nfop/onf_model.py:18-23 */
 
 typedef enum nfopp_status {
@@ -193,6 +193,20 @@ int nfopp_path_interpolate(const float* traj_dev, const float* start_dev, const 
 int nfopp_path_select_best(const float* labels_dev, const float* length_dev, const float* traj_dev, int64_t batch,
                            int32_t poses_per_path, int32_t n_waypoints, int32_t dim, float* best_traj_dev,
                            float* best_length_dev, uint8_t* collides_dev, uint8_t* active_dev, void* stream);
+/* ---- the steps either side of the planner step ----------------------------------------
+ * nfopp_init_trajectories: TrajectoryInitializer.initialize_trajectory (+ initialize_angle and, with
+ *   angles_with_direction != 0, initialize_angle_with_trajectory_direction; nfop/trajectory_initializer.py:12-45) for
+ *   a batch: traj_dev [B, N, D] <- straight line start -> goal with torch.linspace's fp32 rounding, theta along the
+ *   wrapped shortest rotation, optionally pulled towards the travel direction by a 0 -> 1 -> 0 ramp.
+ * nfopp_path_postprocess: PathPostprocessor.process (nfop/ros/path_postprocessor.py:13-69) for a batch of fp32 paths
+ *   path_dev [B, n_points, 3] (3 <= n_points <= 1026): near-duplicate filter, quadratic-spline re-sampling every
+ *   distance_step metres over the chord-length parameter (float64), leading direction flip trimmed.  count_dev[b] =
+ *   poses path b produces (may exceed max_out: only the first max_out are written to out_dev [B, max_out, 3] float64;
+ *   call with max_out = 0 to size the buffer), -1 when fewer than 3 poses survive the filter (the reference raises). */
+int nfopp_init_trajectories(const float* start_dev, const float* goal_dev, int64_t batch, int32_t n_waypoints,
+                            int32_t dim, int32_t angles_with_direction, float* traj_dev, void* stream);
+int nfopp_path_postprocess(const float* path_dev, int64_t batch, int32_t n_points, float minimal_distance,
+                           float distance_step, int32_t max_out, double* out_dev, int32_t* count_dev, void* stream);
 /* torch.optim.Adam single-tensor update on a flat buffer (used for the ONF weights after the gradient
  * all-reduce): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps). */
 int nfopp_adam_step(float* param_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, float beta2,

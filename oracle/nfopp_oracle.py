@@ -630,3 +630,169 @@ def path_select_best(labels, length, traj, best_traj, best_length, active=None):
     best_length = np.where(improve, length, best_length)
     new_active = None if active is None else was_active & ~(~collides & ~improve)
     return collides, best_traj, best_length, new_active
+
+
+# ----------------------------------------------------------------------------------------------------------
+# heading initialisation along the travel direction (csrc/traj_init.hip)
+def initialize_trajectory_directed(start, goal, n):
+    """nfop/trajectory_initializer.py:31-45 (`init_angles_with_trajectory=True`): after the straight-line
+    initialisation, pull each heading towards atan2 of the central difference of the full path, weighted by a
+    0->1->0 ramp (`cat(linspace(0,1,n//2), linspace(1,0,(n+1)//2))`)."""
+    start, goal = np.asarray(start, F32), np.asarray(goal, F32)
+    tr = initialize_trajectory(start, goal, n)
+    full = np.concatenate([start[None], tr, goal[None]]).astype(F32)
+    x = (full[2:, 0] - full[:-2, 0]).astype(F32)
+    y = (full[2:, 1] - full[:-2, 1]).astype(F32)
+    ang = np.arctan2(y, x).astype(F32)
+    w = np.concatenate([linspace_f32(0.0, 1.0, n // 2) if n // 2 > 1 else np.zeros(n // 2, F32),
+                        linspace_f32(1.0, 0.0, (n + 1) // 2) if (n + 1) // 2 > 1 else np.ones((n + 1) // 2, F32)])
+    d = (wrap_angle((ang - tr[:, 2]).astype(F32)) * w).astype(F32)
+    tr[:, 2] = (tr[:, 2] + d).astype(F32)
+    return tr
+
+
+# ----------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) rank 4: path post-processing for the follower (csrc/path_post.hip)
+def _pairwise_sum_f32(a):
+    """numpy's float add.reduce order for a contiguous fp32 vector (pairwise summation: 8 running partial sums
+    over blocks of at most 128 elements, halves split at a multiple of 8) -- the order `np.sum` uses in
+    ros/path_postprocessor.py:29."""
+    a = np.asarray(a, F32)
+    n = len(a)
+    if n < 8:
+        s = F32(0.0)            # numpy starts from -0.0; irrelevant for non-negative terms
+        for v in a:
+            s = F32(s + v)
+        return s
+    if n <= 128:
+        r = [F32(a[j]) for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = F32(r[j] + a[i + j])
+            i += 8
+        s = F32(F32(F32(r[0] + r[1]) + F32(r[2] + r[3])) + F32(F32(r[4] + r[5]) + F32(r[6] + r[7])))
+        for v in a[i:]:
+            s = F32(s + v)
+        return s
+    n2 = n // 2
+    n2 -= n2 % 8
+    return F32(_pairwise_sum_f32(a[:n2]) + _pairwise_sum_f32(a[n2:]))
+
+
+def _quadratic_spline_knots(x):
+    """Knot vector scipy's `make_interp_spline(x, y, k=2)` uses for an even degree (scipy 1.15
+    interpolate/_bsplines.py, default boundary conditions): data-site midpoints without the first and last one,
+    end knots tripled.  interp1d(kind="quadratic") (ros/path_postprocessor.py:50-52) is exactly this spline."""
+    mid = (x[1:] + x[:-1]) / 2.0
+    return np.concatenate([[x[0]] * 3, mid[1:-1], [x[-1]] * 3])
+
+
+def _bspline_basis2(t, ell, x):
+    """The three quadratic B-spline basis values B_{ell-2..ell}(x) for t[ell] <= x < t[ell+1] (de Boor-Cox)."""
+    h = [1.0, 0.0, 0.0]
+    for j in (1, 2):
+        hh = list(h)
+        h[0] = 0.0
+        for n in range(1, j + 1):
+            xb, xa = t[ell + n], t[ell + n - j]
+            if xb == xa:
+                h[n] = 0.0
+                continue
+            w = hh[n - 1] / (xb - xa)
+            h[n - 1] += w * (xb - x)
+            h[n] = w * (x - xa)
+    return h
+
+
+def _find_interval(t, m, x):
+    """Largest ell in [2, m-1] with t[ell] <= x (clamped at both ends: extrapolation uses the end polynomials)."""
+    ell = 2
+    while ell < m - 1 and x >= t[ell + 1]:
+        ell += 1
+    return ell
+
+
+def path_postprocess(path, minimal_distance=0.001, distance_step=0.05):
+    """ros/path_postprocessor.py:13-69 for one fp32 path [n, 3] -> float64 [count', 3].
+
+    Mixed precision as numpy evaluates the reference on an fp32 input: filter/segment lengths/cumsum/unfolded
+    headings in fp32 (python scalars are weak), the normalised parametrisation, spline and output in float64.
+    The quadratic interpolating spline is tridiagonal in its B-spline coefficients (row j touches j-1..j+1), solved
+    here by elimination without pivoting (scipy: LAPACK gbsv) -- agreement to rounding."""
+    tr = np.asarray(path, F32)
+    if len(tr) < 3:
+        return tr.copy()
+    # _filter_trajectory (:35-44): walk backwards, keep interior poses further than minimal_distance from the last kept
+    md = F32(minimal_distance)
+    keep = [len(tr) - 1]
+    prev = tr[-1]
+    for i in range(len(tr) - 2, 0, -1):
+        dx, dy = F32(prev[0] - tr[i, 0]), F32(prev[1] - tr[i, 1])
+        if np.sqrt(F32(F32(dx * dx) + F32(dy * dy))) > md:
+            keep.append(i)
+            prev = tr[i]
+    keep.append(0)
+    tr = tr[keep[::-1]].copy()
+    m = len(tr)
+    if m < 3:
+        raise ValueError("path collapses to fewer than 3 poses: no quadratic spline")
+    seg = (tr[1:, :2] - tr[:-1, :2]).astype(F32)
+    dist = (np.sqrt((seg[:, 0] * seg[:, 0] + seg[:, 1] * seg[:, 1]).astype(F32)) + F32(1e-6)).astype(F32)
+    cum = np.zeros(m, F32)
+    acc = F32(0)
+    for i in range(m - 1):
+        acc = F32(acc + dist[i])
+        cum[i + 1] = acc
+    param = cum.astype(np.float64) / np.float64(cum[-1])
+    total = _pairwise_sum_f32(dist)
+    count = int(F32(total / F32(distance_step)))
+    # unfold_angles (utils/math.py:38-43) in fp32, first heading added in float64, stored back as fp32
+    pi, two_pi = F32(np.pi), F32(2 * np.pi)
+    ang = (np.remainder((tr[:, 2] + pi).astype(F32), two_pi).astype(F32) - pi).astype(F32)
+    d = (ang[1:] - ang[:-1]).astype(F32)
+    d = np.where(d > pi, (d - two_pi).astype(F32), d)
+    d = np.where(d < -pi, (d + two_pi).astype(F32), d).astype(F32)
+    cs = np.zeros(m, F32)
+    acc = F32(0)
+    for i in range(m - 1):
+        acc = F32(acc + d[i])
+        cs[i + 1] = acc
+    tr[:, 2] = (np.float64(ang[0]) + cs.astype(np.float64)).astype(F32)
+    y = tr.astype(np.float64)
+    # interpolating quadratic spline
+    t = _quadratic_spline_knots(param)
+    lower, diag, upper = np.zeros(m), np.ones(m), np.zeros(m)
+    for j in range(1, m - 1):
+        ell = max(2, min(j + 1, m - 1))
+        b = _bspline_basis2(t, ell, param[j])
+        lower[j], diag[j], upper[j] = b[j - 1 - (ell - 2)], b[j - (ell - 2)], b[j + 1 - (ell - 2)]
+    c = y.copy()
+    dd = diag.copy()
+    for j in range(1, m):
+        w = lower[j] / dd[j - 1]
+        dd[j] -= w * upper[j - 1]
+        c[j] -= w * c[j - 1]
+    c[m - 1] /= dd[m - 1]
+    for j in range(m - 2, -1, -1):
+        c[j] = (c[j] - upper[j] * c[j + 1]) / dd[j]
+    if count <= 0:
+        return np.zeros((0, 3))
+    step = 1.0 / (count - 1) if count > 1 else 0.0
+    out = np.zeros((count, 3))
+    for q in range(count):
+        x = 1.0 if (q == count - 1 and count > 1) else q * step
+        ell = _find_interval(t, m, x)
+        b = _bspline_basis2(t, ell, x)
+        out[q] = b[0] * c[ell - 2] + b[1] * c[ell - 1] + b[2] * c[ell]
+    # _find_minimal_filter_index (:54-61): drop the leading poses driven in the other direction (first 6 only)
+    first = 1
+    if count >= 2:
+        delta = out[1:, :2] - out[:-1, :2]
+        dth = np.remainder(out[1:, 2] - out[:-1, 2] + np.pi, 2 * np.pi) - np.pi
+        mean = out[:-1, 2] + dth / 2
+        fwd = np.cos(mean) * delta[:, 0] + np.sin(mean) * delta[:, 1] > 0
+        other = np.nonzero(fwd != fwd[0])[0]
+        if len(other) > 0 and other[0] < 6:
+            first = max(int(other[0]), 1)
+    return out[first:]

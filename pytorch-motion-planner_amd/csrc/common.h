@@ -66,6 +66,7 @@ inline bool make_geom(const nfopp_onf_config* c, OnfGeom* g) {
 
 // ---- device math shared by the kernels ---------------------------------------------------------------------------
 #define NFOPP_PI_F 3.14159274101257324f      /* fp32(pi)   */
+#define NFOPP_PI_D 3.14159265358979323846    /* float64 pi (path post-processing) */
 #define NFOPP_TWO_PI_F 6.28318548202514648f  /* fp32(2 pi) */
 
 // nfop/torch_math.py:5-7: (a + pi) % (2 pi) - pi, remainder with the divisor's sign, all in fp32.

@@ -11,6 +11,7 @@ from .host_utils import (AstarTrajectoryInitializer, AttributeDict, CircleCollis
                          TrajectoryInitializer)
 from .learning import BatchSampler, DeviceCircleChecker, DeviceGridChecker, DeviceRectangleChecker
 from .onf_model import ONF
+from .path_tools import PathPostprocessor, init_trajectories
 from .planner import ConstrainedNERFOptPlanner, ContinuousPlanner, NERFOptPlanner
 
 __all__ = [
@@ -18,5 +19,5 @@ __all__ = [
     "DEFAULT_PARAMETERS", "PlannerFactory", "UniversalFactory", "AstarTrajectoryInitializer", "AttributeDict",
     "CircleCollisionChecker", "CircleDirectedCollisionChecker", "CollisionChecker", "Position2",
     "RectangleCollisionChecker", "TrajectoryInitializer", "ONF", "ConstrainedNERFOptPlanner", "ContinuousPlanner",
-    "NERFOptPlanner",
+    "NERFOptPlanner", "PathPostprocessor", "init_trajectories",
 ]

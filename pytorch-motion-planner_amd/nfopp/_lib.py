@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnfopp_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_TERMS = 8
 TERM_NAMES = ("total", "distance", "softplus_sum", "lambda_dot_c", "c_squared", "boundary", "cm_tanh", "direction")
 
@@ -53,6 +53,10 @@ _SIGNATURES = {
                                               _P, _P, _P]),
     "nfopp_path_select_best": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                               _P, _P, _P, _P, _P]),
+    "nfopp_init_trajectories": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                               _P, _P]),
+    "nfopp_path_postprocess": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                              ctypes.c_int32, _P, _P, _P]),
     "nfopp_onf_train_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(OnfConfigC), ctypes.c_int64]),
     "nfopp_onf_train_grad": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, _P, ctypes.c_int64, ctypes.c_float,
                                             _P, _P, ctypes.c_size_t, _P]),

@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from .engine import TrajectoryEngine, TrajectoryHyper
+from .path_tools import init_trajectories
 
 
 def shard_range(global_batch, rank, world_size):
@@ -125,7 +126,9 @@ class BatchPlanner(object):
     def __init__(self, onf, batch, n_waypoints, hyper, velocity_hessian_weight=0.5, reparametrize_trajectory_freq=10,
                  device="cuda", seed=0, traj_index_offset=0, checker=None, fit_lr=2e-2, fit_betas=(0.9, 0.9),
                  optimize_collision_model_freq=1, trajectory_random_offset=0.02, course_random_offset=1.5,
-                 angle_offset=0.0, random_field_points=10, collision_point_count=100, group=None):
+                 angle_offset=0.0, random_field_points=10, collision_point_count=100, group=None,
+                 init_angles_with_trajectory=False):
+        self.init_angles_with_trajectory = bool(init_angles_with_trajectory)
         self.engine = TrajectoryEngine(onf, batch, n_waypoints, onf.point_dim, hyper, velocity_hessian_weight, device,
                                        seed=seed, traj_index_offset=traj_index_offset)
         self.onf = onf
@@ -149,8 +152,10 @@ class BatchPlanner(object):
                                     h.collision_multipliers_lr, h.boundary_weight, h.collision_beta,
                                     h.direction_delta_weight, h.lr, h.betas, h.eps, boundaries)
         if trajectories is None:
-            trajectories = straight_line_init(starts, goals, eng.N)
-        eng.traj.copy_(torch.as_tensor(np.asarray(trajectories, np.float32)).reshape(eng.traj.shape))
+            # device initialiser (trajectory_initializer.py:12-45); eng.start / eng.goal were uploaded just above
+            init_trajectories(eng.start, eng.goal, eng.N, self.init_angles_with_trajectory and eng.D == 3, out=eng.traj)
+        else:
+            eng.traj.copy_(torch.as_tensor(np.asarray(trajectories, np.float32)).reshape(eng.traj.shape))
         for buf in (eng.lam, eng.cm, eng.adam_m, eng.adam_v):
             if buf is not None:
                 buf.zero_()

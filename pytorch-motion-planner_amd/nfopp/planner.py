@@ -20,7 +20,8 @@ import torch
 
 from . import _lib
 from .engine import TrajectoryEngine, TrajectoryHyper
-from .host_utils import Position2
+from .host_utils import Position2, TrajectoryInitializer
+from .path_tools import init_trajectories
 
 
 class ContinuousPlanner(object):
@@ -321,8 +322,15 @@ class ConstrainedNERFOptPlanner(NERFOptPlanner):
         return self._engine.cm[0]
 
     def _init_trajectory(self):
+        ini = self._trajectory_initializer
+        if type(ini) is TrajectoryInitializer:
+            # the stock initialiser runs as one device kernel (csrc/traj_init.hip); any other object the caller passes
+            # (e.g. an A* seeder) keeps the reference's host protocol below
+            init_trajectories(self._engine.start, self._engine.goal, self._engine.N, ini._init_angles_with_trajectory,
+                              out=self._engine.traj)
+            return
         tr = torch.zeros(self._trajectory.shape[0], 3)
-        self._trajectory_initializer.initialize_trajectory(tr, self._engine.start.cpu(), self._engine.goal.cpu())
+        ini.initialize_trajectory(tr, self._engine.start.cpu(), self._engine.goal.cpu())
         self._engine.traj.copy_(tr)
 
     def _calculate_truth_collision(self, positions):

@@ -515,6 +515,55 @@ def g11_init_and_checkers():
     np.savez_compressed(os.path.join(HERE, "g11_init_checkers.npz"), **out)
 
 
+def g12_init_direction_and_postprocess():
+    """TrajectoryInitializer with init_angles_with_trajectory=True
+    (trajectory_initializer.py:31-45; its debug prints are swallowed) and ros/path_postprocessor.py:13-69 on
+    fp32 planner paths (the ROS adapter hands `Position2.from_vec(planner.get_path())`, goal_planner_adapter.py:56-60)."""
+    import contextlib
+    import io
+    from neural_field_optimal_planner.ros.path_postprocessor import PathPostprocessor
+    out = {}
+    ti = TrajectoryInitializer(None, init_angles_with_trajectory=True)
+    cases = np.asarray([[0.5, 0.5, 0.0, 2.5, 1.5, 0.0], [0.4, 2.6, 3.0, 2.7, 0.5, -3.0],
+                        [1.0, 1.0, -2.0, 1.0, 2.0, 2.5], [2.0, 2.0, 1.0, -1.0, 0.5, -1.0]], F32)
+    for n in (50, 51):
+        res = []
+        for c in cases:
+            tr = torch.zeros(n, 3)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ti.initialize_trajectory(tr, torch.tensor(c[None, :3]), torch.tensor(c[None, 3:]))
+            res.append(tr.numpy().copy())
+        out["dir_traj_n%d" % n] = np.stack(res)
+    out["dir_cases"] = cases
+
+    # post-processor inputs: (a) a planned path (final path of the G9 run), (b) a smooth S-curve with a reversing
+    # first few poses (direction flip trimmed), (c) a path with repeated poses (filtered), (d) a short 3-pose path
+    rng = np.random.default_rng(12)
+    paths = []
+    g9 = np.load(os.path.join(HERE, "g9_full_steps.npz"))
+    paths.append(np.concatenate([g9["start"].reshape(1, 3), g9["k5_traj"], g9["goal"].reshape(1, 3)]).astype(F32))
+    s = np.linspace(0, 1, 120)
+    pb = np.stack([3 * s, np.sin(3 * s), np.arctan2(3 * np.cos(3 * s), 3.0)], 1)
+    pb[:3, 0] = pb[3, 0] + np.asarray([0.12, 0.08, 0.04])            # first poses lie AHEAD: backwards start
+    paths.append(pb.astype(F32))
+    pc = np.stack([2 * s, 0.5 * s ** 2, 0.5 * s + 3.0], 1)            # heading near +-pi: unfold matters
+    pc = np.repeat(pc, 2, axis=0)[:200]
+    pc[1::2, :2] += rng.normal(0, 2e-4, (100, 2))
+    paths.append(pc.astype(F32))
+    paths.append(np.asarray([[0, 0, 0], [0.5, 0.1, 0.3], [1.0, 0.4, 0.6]], F32))
+    pe = np.stack([20 * s, 10 * np.sin(2 * s), rng.uniform(-3, 3, 120)], 1)   # long path, wild headings
+    paths.append(pe.astype(F32))
+    pp = PathPostprocessor()
+    for i, path in enumerate(paths):
+        res = pp.process(Position2.from_vec(path.copy())).as_vec()
+        out["post_in_%d" % i] = path
+        out["post_out_%d" % i] = np.asarray(res)
+    pp2 = PathPostprocessor(minimal_distance=0.01, distance_step=0.11)
+    out["post_out_alt_1"] = np.asarray(pp2.process(Position2.from_vec(paths[1].copy())).as_vec())
+    out["post_alt_params"] = np.asarray([0.01, 0.11])
+    np.savez_compressed(os.path.join(HERE, "g12_init_dir_postprocess.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     g1_onf()
@@ -529,6 +578,7 @@ if __name__ == "__main__":
     g9_full_steps()
     g10_planner2d()
     g11_init_and_checkers()
+    g12_init_direction_and_postprocess()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
