@@ -34,7 +34,11 @@ struct OnfKernelArgs {
   float* loss_partial;  // [grid * WAVES]
 };
 
+int query_cus();
 int launch_onf_kernel(const OnfKernelArgs& a, hipStream_t stream);
+// csrc/onf_split.hip: the same kernels with every GEMM issued as bf16x3 split-precision products (mode 0 / 2)
+int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only);
+bool onf_split_enabled();
 int launch_onf_logits_kernel(const OnfKernelArgs& a, hipStream_t stream);
 int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);
 int onf_train_grid_upper_bound();

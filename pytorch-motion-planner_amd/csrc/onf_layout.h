@@ -1,0 +1,139 @@
+// LDS image layout, staging and feature evaluation shared by the fused ONF kernels: csrc/onf_fused.hip (fp32 MFMA)
+// and csrc/onf_split.hip (bf16x3 split-precision MFMA).  See the header comment of onf_fused.hip for the design.
+#pragma once
+#include <type_traits>
+
+#include "onf_kernel.h"
+
+namespace nfopp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H = NFOPP_HIDDEN;
+constexpr int HT = 7;     // hidden tiles of 16 (tile 6 carries features 96..99 in rows (g, r = 0))
+constexpr int S2 = 129;   // LDS row stride of W2 (floats), = 1 mod 32
+constexpr int THREADS = 512;
+constexpr int WAVES = THREADS / 64;
+constexpr int KSTEPS = 25;  // hidden k-steps: ks -> tile ks>>2, register ks&3 (tile 6 only register 0)
+
+
+template <int NKT>
+struct Lds {
+  // layout P spreads a pair of input tiles over a block of 32 features, so an odd NKT still indexes a full block
+  static constexpr int NF = 32 * ((NKT + 1) / 2);           // input-feature slots (>= fin, zero padded)
+  static constexpr int S1 = (NF > 128) ? 225 : 129;         // = 1 mod 32, > NF
+  static constexpr int W1 = 0;
+  static constexpr int W2 = W1 + H * S1;
+  static constexpr int FT = ((W2 + H * S2 + 3) / 4) * 4;  // feature table, FTS floats per input feature
+  static constexpr int FTS = 12;                          // (wx wx wy wy | b b fr fr | qh qh w3b w3b): packed-math pairs
+  static constexpr int B1 = FT + NF * FTS;                // 112 each, D-layout indexable (see fill)
+  static constexpr int B2 = B1 + 16 * HT;
+  static constexpr int W3A = B2 + 16 * HT;
+  static constexpr int W3B = W3A + 16 * HT;               // NF skip weights
+  static constexpr int ISA = W3B + NF;                    // NF flags: 1.0 = angle feature
+  static constexpr int TOTAL = ISA + NF;
+  static constexpr size_t BYTES = size_t(TOTAL) * 4;
+};
+
+__device__ __forceinline__ int base_p(int t) { return 32 * (t >> 1) + 8 * (t & 1); }
+
+// max(x, 0) as ONE integer instruction: for IEEE floats max_i32(bits, 0) clears every negative value (and -0)
+// and keeps every positive one.  (fmaxf lowers to canonicalize + max; an inline-asm v_max_f32 would hide the
+// VALU->MFMA operand hazard from hipcc.)
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- exact three-level bf16 split: x = hi + mid + lo, every level the top 16 bits of the running residual --------
+// (truncation keeps 8 significant bits per level; the residual subtractions are exact in fp32)
+__host__ __device__ __forceinline__ unsigned split_level(float& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned top = __float_as_uint(x) & 0xffff0000u;
+  x = x - __uint_as_float(top);
+#else
+  unsigned bits; __builtin_memcpy(&bits, &x, 4);
+  const unsigned top = bits & 0xffff0000u;
+  float t; __builtin_memcpy(&t, &top, 4);
+  x = x - t;
+#endif
+  return top >> 16;
+}
+__device__ __forceinline__ float pack_hi_mid(float w) {
+  const unsigned hi = split_level(w), mid = split_level(w);
+  return __uint_as_float((hi << 16) | mid);
+}
+__device__ __forceinline__ unsigned lo_level(float w) {
+  split_level(w); split_level(w);
+  return __float_as_uint(w) >> 16;   // third level: exactly representable, low half-word is zero
+}
+
+// ---- stage the flat parameter buffer into LDS ---------------------------------------------------------------
+// PACKED: weight words hold (bf16 hi | bf16 mid) of the weight instead of its fp32 value (onf_split.hip)
+template <int NKT, bool TRAIN, bool PACKED = false>
+__device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
+  using L = Lds<NKT>;
+  const OnfGeom& g = a.geom;
+  const float* P = a.params;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < H * L::S1; idx += THREADS) {
+    int row = idx / L::S1, col = idx - row * L::S1;
+    const float w = col < g.fin ? P[g.off_w1 + row * g.fin + col] : 0.0f;
+    lds[L::W1 + idx] = PACKED ? pack_hi_mid(w) : w;
+  }
+  for (int idx = tid; idx < H * S2; idx += THREADS) {
+    int row = idx / S2, col = idx - row * S2;
+    const float w = col < H ? P[g.off_w2 + row * H + col] : 0.0f;
+    lds[L::W2 + idx] = PACKED ? pack_hi_mid(w) : w;
+  }
+  for (int f = tid; f < L::NF; f += THREADS) {
+    // feature = sin(arg + q*pi/2), q = 1 for cosine features, stored as qh = q * NFOPP_Q_UNIT; every scalar is
+    // stored twice (a packed-math pair)
+    float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, w3b = 0.f, qh = 0.f, is_angle = 0.f;
+    if (f < g.n_enc) {
+      wx = P[g.off_we + 2 * f];
+      wy = P[g.off_we + 2 * f + 1];
+      b = g.off_be >= 0 ? P[g.off_be + f] : 0.0f;
+      qh = (g.n_enc > g.n_sin && f >= g.n_sin) ? NFOPP_Q_UNIT : 0.0f;
+      w3b = P[g.off_w3 + H + f];
+    } else if (f < g.fin) {
+      int k = f - g.n_enc;
+      b = P[g.off_ang_b + k];
+      fr = P[g.off_ang_f + k];
+      qh = k >= g.ang_dim ? NFOPP_Q_UNIT : 0.0f;
+      is_angle = 1.0f;
+      w3b = P[g.off_w3 + H + f];
+    } else if (TRAIN && f == a.aug_feature) {
+      qh = NFOPP_Q_UNIT;  // all weights zero: sin(0 + pi/2) = 1
+    }
+    float* e = lds + L::FT + L::FTS * f;
+    e[0] = e[1] = wx; e[2] = e[3] = wy; e[4] = e[5] = b; e[6] = e[7] = fr;
+    e[8] = e[9] = qh; e[10] = e[11] = w3b;
+    lds[L::W3B + f] = w3b;
+    lds[L::ISA + f] = is_angle;
+  }
+  // hidden-indexed vectors: entries 0..95 natural; entries 96 + 4g + r hold feature 96+g for r == 0, else 0
+  for (int k = tid; k < 16 * HT; k += THREADS) {
+    int h = k < 96 ? k : (((k - 96) & 3) == 0 ? 96 + ((k - 96) >> 2) : -1);
+    lds[L::B1 + k] = h >= 0 ? P[g.off_b1 + h] : 0.0f;
+    lds[L::B2 + k] = h >= 0 ? P[g.off_b2 + h] : 0.0f;
+    lds[L::W3A + k] = h >= 0 ? P[g.off_w3 + h] : 0.0f;
+  }
+}
+
+// Two input features at once (packed fp32): table entries e0 = (wx, wy, b, fr), (qh, is_angle) per slot,
+// points (ux, uy, th) per slot; DERIV adds half a turn of pi/2... i.e. evaluates d feature / d arg (L1T epilogue).
+template <bool MAY_BE_ANGLE, bool DERIV>
+__device__ __forceinline__ f32x2 features2(f32x2 wx, f32x2 wy, f32x2 b, f32x2 fr, f32x2 qh, f32x2 is_angle,
+                                           f32x2 ux, f32x2 uy, f32x2 th) {
+  f32x2 arg = fma2(wx, ux, fma2(wy, uy, b));  // encoding_layer: W_e u + b_e (onf_model.py:39)
+  if (MAY_BE_ANGLE) {
+    const f32x2 za = (th + b) * fr;            // (theta + b) * f (angle_encoder.py:16)
+    arg.x = is_angle.x != 0.0f ? za.x : arg.x;
+    arg.y = is_angle.y != 0.0f ? za.y : arg.y;
+  }
+  return sin_halfturns2(arg, DERIV ? qh + splat2(NFOPP_Q_UNIT) : qh);
+}
+
+}  // namespace nfopp

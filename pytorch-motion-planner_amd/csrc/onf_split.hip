@@ -1,0 +1,660 @@
+// Fused ONF forward + input-gradient kernel for gfx950 with every GEMM issued on the bf16 matrix pipe as an EXACT
+// three-level split of the fp32 operands ("bf16x3").
+//
+// Why: on gfx950 the fp32 MFMA shares the vector ALU (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for onf_fused.hip: matrix and
+// vector work serialise), and runs at 64 FLOP/clk/SIMD.  v_mfma_f32_16x16x32_bf16 runs at 1024 FLOP/clk/SIMD on its own
+// pipe and leaves half of its 16 cycles to vector issue.  Every fp32 value x is split without error into
+//      x = hi + mid + lo,   each level the top 16 bits (a bf16) of the running residual (8 significant bits a level),
+// and a product a*b is accumulated in fp32 as  a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1.  The three dropped partial
+// products are below 2^-24 |ab| -- smaller than the rounding of an fp32 multiply -- so the result is fp32-faithful
+// (measured: 10x closer to float64 than a sequential fp32 dot product, tools/micro + tests/test_gpu_split_path.py),
+// at 6/16 of the fp32 MFMA time.
+//
+// What changes against onf_fused.hip (same points-on-N / features-on-M orientation, same LDS images and layouts P/Q,
+// same accumulator-as-next-operand chaining, same feature evaluation and epilogues):
+//  * an LDS weight word holds (bf16 hi | bf16 mid) of the weight instead of its fp32 value: the images keep their
+//    size, their [row][col] addressing and therefore every conflict-free read pattern of the fp32 kernel;
+//  * the third level does not fit in LDS (6 bytes per weight): a small prep kernel writes it to a per-device blob in
+//    exactly the order the lanes consume it (16 bytes per lane and step, coalesced, L2-resident, 160 KB per ONF);
+//  * one MFMA step covers 32 k values = 8 per lane group: the lane gathers its 8 weight words with ds_read_b32, packs
+//    the hi and the mid fragments with 8 v_perm_b32, fetches the lo fragment with one global load, and issues the 6
+//    products per point tile; activations are split by the vector ALU (5.5 instructions per element) which now
+//    overlaps the matrix pipe.
+// k blocks pair the accumulator tiles (2kb, 2kb+1): element j of a lane's fragment is register j&3 of tile 2kb+(j>>2).
+#include <stdlib.h>
+
+#include "onf_layout.h"
+
+namespace nfopp {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfmab(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc += A * B with both operands in three levels (the six partial products above 2^-24)
+__device__ __forceinline__ f32x4 mfma6(const u32x4& ah, const u32x4& am, const u32x4& al, const u32x4& bh,
+                                       const u32x4& bm, const u32x4& bl, f32x4 c) {
+  c = mfmab(al, bh, c);   // smallest terms first
+  c = mfmab(ah, bl, c);
+  c = mfmab(am, bm, c);
+  c = mfmab(am, bh, c);
+  c = mfmab(ah, bm, c);
+  c = mfmab(ah, bh, c);
+  return c;
+}
+
+// 8 fp32 values -> three packed bf16 fragments (element j in half-word j)
+__device__ __forceinline__ void split8(const float x[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const unsigned a = __float_as_uint(x[2 * p]), b = __float_as_uint(x[2 * p + 1]);
+    hi[p] = __builtin_amdgcn_perm(b, a, 0x07060302);
+    const float ra = x[2 * p] - __uint_as_float(a & 0xffff0000u), rb = x[2 * p + 1] - __uint_as_float(b & 0xffff0000u);
+    const unsigned ua = __float_as_uint(ra), ub = __float_as_uint(rb);
+    mid[p] = __builtin_amdgcn_perm(ub, ua, 0x07060302);
+    const float la = ra - __uint_as_float(ua & 0xffff0000u), lb = rb - __uint_as_float(ub & 0xffff0000u);
+    lo[p] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302);
+  }
+}
+
+// 8 (hi | mid) weight words -> the hi and the mid fragment
+__device__ __forceinline__ void pack_words(const float w[8], u32x4& hi, u32x4& mid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const unsigned a = __float_as_uint(w[2 * p]), b = __float_as_uint(w[2 * p + 1]);
+    hi[p] = __builtin_amdgcn_perm(b, a, 0x07060302);
+    mid[p] = __builtin_amdgcn_perm(b, a, 0x05040100);
+  }
+}
+
+// ---- third-level blob: [gemm][step][lane] 16 bytes --------------------------------------------------------------
+template <int NKT>
+struct Blob {
+  static constexpr int NKB = (NKT + 1) / 2;   // input k blocks (pairs of input tiles)
+  static constexpr int HKB = 4;               // hidden k blocks: tiles (0,1) (2,3) (4,5) (6,-)
+  static constexpr int L1 = 0;                // step = kb * HT + mt
+  static constexpr int L2 = L1 + NKB * HT;    // step = kb * HT + mt
+  static constexpr int L2T = L2 + HKB * HT;   // step = kb * HT + mt
+  static constexpr int L1T = L2T + HKB * HT;  // step = mt * HKB + kb
+  static constexpr int STEPS = L1T + NKT * HKB;
+  static constexpr size_t BYTES = size_t(STEPS) * 64 * 16;
+};
+
+struct LaneGeom {
+  int i, g, gi, ri, colP, colQ, rowposP, rowposQ;
+  __device__ explicit LaneGeom(int lane) {
+    i = lane & 15; g = lane >> 4; gi = i >> 2; ri = i & 3;
+    colP = 16 * (g & 1) + 4 * (g >> 1); colQ = 8 * (g & 1) + 4 * (g >> 1);
+    rowposP = 16 * (gi & 1) + 4 * (gi >> 1) + ri; rowposQ = 8 * (gi & 1) + 4 * (gi >> 1) + ri;
+  }
+};
+
+// the hidden index a lane group contributes as k element j of hidden k block kb, under layout Q (h1) or P (h2); -1: none
+__device__ __forceinline__ int hidden_k(int kb, int j, int g, bool layout_p, int colP, int colQ) {
+  const int t = 2 * kb + (j >> 2), r = j & 3;
+  if (t < 6) return layout_p ? base_p(t) + r + colP : 16 * t + r + colQ;
+  return (t == 6 && r == 0) ? 96 + g : -1;
+}
+
+template <int NKT>
+__global__ __launch_bounds__(64) void split_prep_kernel(const OnfGeom geo, const float* __restrict__ P, u32x4* blob) {
+  using B = Blob<NKT>;
+  const int step = blockIdx.x, lane = threadIdx.x;
+  const LaneGeom q(lane);
+  auto w1 = [&](int row, int col) { return (row >= 0 && col < geo.fin) ? P[geo.off_w1 + row * geo.fin + col] : 0.0f; };
+  auto w2 = [&](int row, int col) { return (row >= 0 && col >= 0) ? P[geo.off_w2 + row * H + col] : 0.0f; };
+  float w[8];
+  if (step < B::L2) {                     // L1: a1 = W1 in
+    const int kb = (step - B::L1) / HT, mt = (step - B::L1) % HT;
+    const int row = mt < 6 ? 16 * mt + q.rowposQ : 96 + q.gi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = w1(row, base_p(2 * kb + (j >> 2)) + q.colP + (j & 3));
+  } else if (step < B::L2T) {             // L2: a2 = W2 h1
+    const int kb = (step - B::L2) / HT, mt = (step - B::L2) % HT;
+    const int row = mt < 6 ? base_p(mt) + q.rowposP : 96 + q.gi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = w2(row, hidden_k(kb, j, q.g, false, q.colP, q.colQ));
+  } else if (step < B::L1T) {             // L2T: dh1 = W2^T dh2
+    const int kb = (step - B::L2T) / HT, mt = (step - B::L2T) % HT;
+    const int col = mt < 6 ? 16 * mt + q.rowposQ : 96 + q.gi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = w2(hidden_k(kb, j, q.g, true, q.colP, q.colQ), col);
+  } else {                                // L1T: din = W1^T dh1
+    const int mt = (step - B::L1T) / B::HKB, kb = (step - B::L1T) % B::HKB;
+    const int col = base_p(mt) + q.rowposP;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = w1(hidden_k(kb, j, q.g, false, q.colP, q.colQ), col);
+  }
+  u32x4 out;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) out[p] = lo_level(w[2 * p]) | (lo_level(w[2 * p + 1]) << 16);
+  blob[step * 64 + lane] = out;
+}
+
+// MODE 0: forward + input gradient (planner step)   2: forward only (logits)
+template <int NKT, int NT, int MODE>
+__global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelArgs a, const u32x4* __restrict__ blob) {
+  static_assert(MODE == 0 || MODE == 2, "the training pass stays on the fp32 kernel");
+  constexpr bool FWD_ONLY = MODE == 2;
+  using L = Lds<NKT>;
+  using B = Blob<NKT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds<NKT, false, true>(lds, a);
+  __syncthreads();
+
+  const OnfGeom& geo = a.geom;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4, gi = i >> 2, ri = i & 3;
+  const int colP = 16 * (g & 1) + 4 * (g >> 1), colQ = 8 * (g & 1) + 4 * (g >> 1);
+  const int rowposP = 16 * (gi & 1) + 4 * (gi >> 1) + ri, rowposQ = 8 * (gi & 1) + 4 * (gi >> 1) + ri;
+  const int first_angle_kb = geo.n_ang ? geo.n_enc / 32 : B::NKB;   // first k block that can hold an angle feature
+
+  const float* W1 = lds + L::W1;
+  const float* W2 = lds + L::W2;
+  constexpr int S1 = L::S1;
+  constexpr int CH = WAVES * 16 * NT;
+  const long long n_chunks = (a.n_points + CH - 1) / CH;
+  const float b3 = a.params[geo.off_b3];
+  const u32x4* lob = blob + lane;
+
+  for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // ---------------------------------------------------------------- sample / load the wave's points
+    float ux[NT], uy[NT], th[NT];
+    long long pidx[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      long long p = chunk * CH + (wave * NT + tl) * 16 + i;
+      pidx[tl] = p;
+      if (p >= a.n_points) p = a.n_points - 1;
+      float x, y, ang = 0.f;
+      if (a.points) {
+        const float* q = a.points + p * geo.point_dim;
+        x = q[0]; y = q[1];
+        if (geo.point_dim == 3) ang = q[2];
+      } else {
+        const int nseg = a.n_way - 1;
+        long long b;
+        int j;
+        if (a.n_points < 0x7fffffffLL) {
+          const unsigned b32 = (unsigned)p / (unsigned)nseg;
+          b = b32;
+          j = (int)((unsigned)p - b32 * (unsigned)nseg);
+        } else {
+          b = p / nseg;
+          j = (int)(p - b * nseg);
+        }
+        float tt;
+        if (a.t_mode == 0) {
+          tt = a.t[p];
+        } else {
+          unsigned long long gp = (unsigned long long)((a.traj_index_offset + b) * nseg + j);
+          tt = philox_uniform(a.seed, gp, a.rng_offset);
+          if (g == 0 && pidx[tl] < a.n_points) a.t[p] = tt;
+        }
+        const float* qa = a.traj + (b * a.n_way + j) * a.dim;
+        const float* qb = qa + a.dim;
+        if (a.dim == 3) {
+          float dx = qa[0] - qb[0], dy = qa[1] - qb[1], dth = wrap_angle(qa[2] - qb[2]);
+          x = qb[0] + tt * dx; y = qb[1] + tt * dy; ang = qb[2] + tt * dth;
+        } else {
+          float omt = 1.0f - tt;
+          x = qb[0] * omt + qa[0] * tt; y = qb[1] * omt + qa[1] * tt;
+        }
+      }
+      ux[tl] = (x - geo.mean) / geo.sigma;
+      uy[tl] = (y - geo.mean) / geo.sigma;
+      th[tl] = ang;
+    }
+
+    // ---------------------------------------------------------------- L1: a1 = W1 in + b1, features just-in-time
+    f32x4 acc1[NT][HT];
+    float skip[NT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L::B1 + (mt < 6 ? 16 * mt + colQ : 96 + 4 * g));
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = bias;
+    }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) skip[tl] = 0.f;
+
+    const float* w1a = W1 + rowposQ * S1 + colP;
+    const float* w1b = w1a + 64 * S1;
+    const float* w1c = W1 + (96 + gi) * S1 + colP;
+    const float* ftl = lds + L::FT + L::FTS * colP;
+    const float* isl = lds + L::ISA + colP;
+
+    auto l1_block = [&](auto ang_c, int kb) __attribute__((always_inline)) {
+      constexpr bool ANG = decltype(ang_c)::value;
+      const int off = 32 * kb;   // base_p(2 kb); the second tile of the pair sits 8 columns further
+      // the lane's 8 features of this k block for every point tile: element j = feature off + 8 (j >> 2) + colP + (j & 3)
+      u32x4 bh[NT], bm[NT], bl[NT];
+      {
+        float fv[NT][8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float* fte = ftl + L::FTS * (off + 8 * half);
+          if (NT == 2) {
+            const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
+            f32x2 sk = {skip[0], skip[NT - 1]};
+            f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};
+            if (ANG) isa4 = *reinterpret_cast<const f32x4*>(isl + off + 8 * half);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const f32x4 e0 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r);
+              const f32x4 e1 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 4);
+              const f32x4 e2 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 8);
+              const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
+              const f32x2 qh = {e2.x, e2.y}, w3 = {e2.z, e2.w};
+              const f32x2 v = features2<ANG, false>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
+              sk = fma2(w3, v, sk);
+              fv[0][4 * half + r] = v.x; fv[NT - 1][4 * half + r] = v.y;
+            }
+            skip[0] = sk.x; skip[NT - 1] = sk.y;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const float* ea = fte + L::FTS * r;
+              const float* eb = ea + L::FTS;
+              const f32x2 ux2 = splat2(ux[0]), uy2 = splat2(uy[0]), th2 = splat2(th[0]);
+              const f32x2 wx = {ea[0], eb[0]}, wy = {ea[2], eb[2]}, bb = {ea[4], eb[4]}, fr = {ea[6], eb[6]};
+              const f32x2 qh = {ea[8], eb[8]}, isa = {isl[off + 8 * half + r], isl[off + 8 * half + r + 1]};
+              const f32x2 v = features2<ANG, false>(wx, wy, bb, fr, qh, isa, ux2, uy2, th2);
+              skip[0] = fmaf(ea[10], v.x, skip[0]);
+              skip[0] = fmaf(eb[10], v.y, skip[0]);
+              fv[0][4 * half + r] = v.x; fv[0][4 * half + r + 1] = v.y;
+            }
+          }
+        }
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) split8(fv[tl], bh[tl], bm[tl], bl[tl]);
+      }
+      const float* pa = w1a + off;
+      const float* pb = w1b + off;
+      const float* pc = w1c + off;
+      const u32x4* lo = lob + (B::L1 + kb * HT) * 64;
+      // weight words of tile mt+1 are fetched while tile mt multiplies (the fences keep hipcc from hoisting every load
+      // of the unrolled loop to the top, which spills)
+      float wn[8];
+      u32x4 aln;
+      auto fetch = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = 8 * (j >> 2) + (j & 3);
+          wn[j] = mt < 4 ? pa[mt * 16 * S1 + c] : (mt < 6 ? pb[(mt - 4) * 16 * S1 + c] : pc[c]);
+        }
+        aln = lo[mt * 64];
+      };
+      fetch(0);
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = wn[j];
+        const u32x4 al = aln;
+        if (mt + 1 < HT) fetch(mt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 ah, am;
+        pack_words(w, ah, am);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc1[tl][mt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll 1
+    for (int kb = 0; kb < first_angle_kb; ++kb) l1_block(std::false_type{}, kb);
+#pragma unroll 1
+    for (int kb = first_angle_kb; kb < B::NKB; ++kb) l1_block(std::true_type{}, kb);
+
+    // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
+    f32x4 acc2[NT][HT];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L::B2 + (mt < 6 ? base_p(mt) + colP : 96 + 4 * g));
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = bias;
+    }
+    {
+      int rowoff2[HT];  // rows in h2 layout P
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) rowoff2[mt] = (mt < 6 ? base_p(mt) + rowposP : 96 + gi) * S2;
+      float wn[8];
+      u32x4 aln;
+      auto fetch = [&](int kb, int mt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int t = 2 * kb + (j >> 2), r = j & 3;
+          wn[j] = t < 6 ? W2[rowoff2[mt] + 16 * t + r + colQ] : ((t == 6 && r == 0) ? W2[rowoff2[mt] + 96 + g] : 0.0f);
+        }
+        aln = lob[(B::L2 + kb * HT + mt) * 64];
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int kb = 0; kb < B::HKB; ++kb) {
+        u32x4 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+          float hv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int t = 2 * kb + (j >> 2), r = j & 3;
+            hv[j] = (t < 6 || (t == 6 && r == 0)) ? relu1(acc1[tl][t < HT ? t : 0][r]) : 0.0f;
+          }
+          split8(hv, bh[tl], bm[tl], bl[tl]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          float w[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[j] = wn[j];
+          const u32x4 al = aln;
+          if (mt + 1 < HT) fetch(kb, mt + 1);
+          else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          u32x4 ah, am;
+          pack_words(w, ah, am);
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc2[tl][mt]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+
+    // ---------------------------------------------------------------- logit and dh2 = W3a * [a2 > 0]
+    float logit[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) logit[tl] = skip[tl];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      const f32x4 w3a = *reinterpret_cast<const f32x4*>(lds + L::W3A + (mt < 6 ? base_p(mt) + colP : 96 + 4 * g));
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a2 = acc2[tl][mt][r];
+          const float d2 = a2 > 0.0f ? w3a[r] : 0.0f;   // dh2 = W3a * [a2 > 0]
+          logit[tl] = fmaf(d2, a2, logit[tl]);          // = W3a * relu(a2)
+          acc2[tl][mt][r] = d2;
+        }
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      logit[tl] += __shfl_xor(logit[tl], 16);
+      logit[tl] += __shfl_xor(logit[tl], 32);
+      logit[tl] += b3;
+    }
+    if (FWD_ONLY) {
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl)
+        if (g == 0 && pidx[tl] < a.n_points)
+          *reinterpret_cast<f32x4*>(a.out4 + pidx[tl] * 4) = f32x4{logit[tl], 0.f, 0.f, 0.f};
+      continue;
+    }
+
+    // ---------------------------------------------------------------- L2T: dh1 = (W2^T dh2) * [a1 > 0]
+    {
+      // the sign pattern of a1 is all L2T needs from it: 28 bits per point tile free its 28 registers
+      unsigned mask1[NT];
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) {
+        mask1[tl] = 0;
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mask1[tl] |= (acc1[tl][mt][r] > 0.0f ? 1u : 0u) << (4 * mt + r);
+      }
+      f32x4 accd[NT][HT];
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int coloff[HT];  // output rows = h1 layout Q -> column of W2
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) coloff[mt] = mt < 6 ? 16 * mt + rowposQ : 96 + gi;
+      float wn[8];
+      u32x4 aln;
+      auto fetch = [&](int kb, int mt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int t = 2 * kb + (j >> 2), r = j & 3;
+          wn[j] = t < 6 ? W2[(base_p(t) + r + colP) * S2 + coloff[mt]]
+                        : ((t == 6 && r == 0) ? W2[(96 + g) * S2 + coloff[mt]] : 0.0f);
+        }
+        aln = lob[(B::L2T + kb * HT + mt) * 64];
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int kb = 0; kb < B::HKB; ++kb) {
+        u32x4 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+          float hv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int t = 2 * kb + (j >> 2), r = j & 3;
+            hv[j] = (t < 6 || (t == 6 && r == 0)) ? acc2[tl][t < HT ? t : 0][r] : 0.0f;
+          }
+          split8(hv, bh[tl], bm[tl], bl[tl]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          float w[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[j] = wn[j];
+          const u32x4 al = aln;
+          if (mt + 1 < HT) fetch(kb, mt + 1);
+          else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          u32x4 ah, am;
+          pack_words(w, ah, am);
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], accd[tl][mt]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc1[tl][mt][r] = ((mask1[tl] >> (4 * mt + r)) & 1u) ? accd[tl][mt][r] : 0.0f;  // dh1
+    }
+
+    // ---------------------------------------------------------------- L1T: din = W1^T dh1 + W3b, then the chain rule
+    float gx[NT], gy[NT], gt[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) gx[tl] = gy[tl] = gt[tl] = 0.f;
+    // dh1 in three levels, once for all output tiles: 4 k blocks x NT
+    u32x4 dh[B::HKB][NT], dm[B::HKB][NT], dl[B::HKB][NT];
+#pragma unroll
+    for (int kb = 0; kb < B::HKB; ++kb)
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int t = 2 * kb + (j >> 2), r = j & 3;
+          hv[j] = (t < 6 || (t == 6 && r == 0)) ? acc1[tl][t < HT ? t : 0][r] : 0.0f;
+        }
+        split8(hv, dh[kb][tl], dm[kb][tl], dl[kb][tl]);
+      }
+    const int rowkQ = colQ * S1;
+
+    auto l1t_tile = [&](auto ang_c, int mt) __attribute__((always_inline)) {
+      constexpr bool ANG = decltype(ang_c)::value;
+      const int fbase = base_p(mt) + colP;
+      const int colA = base_p(mt) + rowposP;
+      const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
+      f32x4 acc[NT];
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
+      const u32x4* lo = lob + (B::L1T + mt * B::HKB) * 64;
+      float wn[8];
+      u32x4 aln;
+      auto fetch = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int t = 2 * kb + (j >> 2), r = j & 3;
+          wn[j] = t < 6 ? W1[rowkQ + (16 * t + r) * S1 + colA] : ((t == 6 && r == 0) ? W1[(96 + g) * S1 + colA] : 0.0f);
+        }
+        aln = lo[kb * 64];
+      };
+      fetch(0);
+#pragma unroll
+      for (int kb = 0; kb < B::HKB; ++kb) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = wn[j];
+        const u32x4 al = aln;
+        if (kb + 1 < B::HKB) fetch(kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 ah, am;
+        pack_words(w, ah, am);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma6(ah, am, al, dh[kb][tl], dm[kb][tl], dl[kb][tl], acc[tl]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const float* fte = lds + L::FT + L::FTS * fbase;
+      if (NT == 2) {
+        const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
+        f32x2 gx2 = {gx[0], gx[NT - 1]}, gy2 = {gy[0], gy[NT - 1]}, gt2 = {gt[0], gt[NT - 1]};
+        f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};
+        if (ANG) isa4 = *reinterpret_cast<const f32x4*>(lds + L::ISA + fbase);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 4);
+          const f32x2 qh = *reinterpret_cast<const f32x2*>(fte + L::FTS * r + 8);
+          const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
+          const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
+          const f32x2 de = f32x2{acc[0][r], acc[NT - 1][r]} * cof;
+          gx2 = fma2(de, wx, gx2);
+          gy2 = fma2(de, wy, gy2);
+          if (ANG) gt2 = fma2(de, fr, gt2);
+        }
+        gx[0] = gx2.x; gx[NT - 1] = gx2.y; gy[0] = gy2.x; gy[NT - 1] = gy2.y; gt[0] = gt2.x; gt[NT - 1] = gt2.y;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const float* ea = fte + L::FTS * r;
+          const float* eb = ea + L::FTS;
+          const f32x2 wx = {ea[0], eb[0]}, wy = {ea[2], eb[2]}, bb = {ea[4], eb[4]}, fr = {ea[6], eb[6]};
+          const f32x2 qh = {ea[8], eb[8]}, isa = {lds[L::ISA + fbase + r], lds[L::ISA + fbase + r + 1]};
+          const f32x2 ux2 = splat2(ux[0]), uy2 = splat2(uy[0]), th2 = splat2(th[0]);
+          const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, isa, ux2, uy2, th2);
+          const f32x2 de = f32x2{acc[0][r], acc[0][r + 1]} * cof;
+          gx[0] = fmaf(de.x, wx.x, gx[0]); gx[0] = fmaf(de.y, wx.y, gx[0]);
+          gy[0] = fmaf(de.x, wy.x, gy[0]); gy[0] = fmaf(de.y, wy.y, gy[0]);
+          if (ANG) { gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]); }
+        }
+      }
+    };
+    const int first_angle_kt = 2 * first_angle_kb < NKT ? 2 * first_angle_kb : NKT;
+#pragma unroll 1
+    for (int mt = 0; mt < first_angle_kt; ++mt) l1t_tile(std::false_type{}, mt);
+#pragma unroll 1
+    for (int mt = first_angle_kt; mt < NKT; ++mt) l1t_tile(std::true_type{}, mt);
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      gx[tl] += __shfl_xor(gx[tl], 16); gx[tl] += __shfl_xor(gx[tl], 32);
+      gy[tl] += __shfl_xor(gy[tl], 16); gy[tl] += __shfl_xor(gy[tl], 32);
+      gt[tl] += __shfl_xor(gt[tl], 16); gt[tl] += __shfl_xor(gt[tl], 32);
+      if (a.out4 && g == 0 && pidx[tl] < a.n_points) {
+        f32x4 o = {logit[tl], gx[tl] / geo.sigma, gy[tl] / geo.sigma, gt[tl]};
+        *reinterpret_cast<f32x4*>(a.out4 + pidx[tl] * 4) = o;
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+static int g_split_mode = -1;   // -1: read NFOPP_MATRIX_PATH on first use; 0: fp32 MFMA; 1: bf16x3 split
+
+bool onf_split_enabled() {
+  if (g_split_mode < 0) {
+    const char* e = getenv("NFOPP_MATRIX_PATH");
+    g_split_mode = (e && (e[0] == 's' || e[0] == 'b' || e[0] == '1')) ? 1 : 0;   // "split" / "bf16x3" / "1"
+  }
+  return g_split_mode == 1;
+}
+
+constexpr int MAX_DEVICES = 16;
+static void* g_blob[MAX_DEVICES] = {};
+static size_t g_blob_bytes[MAX_DEVICES] = {};
+
+static int blob_for_device(size_t bytes, u32x4** out) {
+  int dev = 0;
+  NFOPP_HIP(hipGetDevice(&dev));
+  NFOPP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index %d out of range", dev);
+  if (g_blob_bytes[dev] < bytes) {
+    if (g_blob[dev]) NFOPP_HIP(hipFree(g_blob[dev]));
+    g_blob[dev] = nullptr; g_blob_bytes[dev] = 0;
+    NFOPP_HIP(hipMalloc(&g_blob[dev], bytes));
+    g_blob_bytes[dev] = bytes;
+  }
+  *out = reinterpret_cast<u32x4*>(g_blob[dev]);
+  return NFOPP_OK;
+}
+
+template <int NKT, int NT, int MODE>
+static int launch_split_t(const OnfKernelArgs& a, hipStream_t stream) {
+  using L = Lds<NKT>;
+  using B = Blob<NKT>;
+  static bool attr_set = false;
+  auto kern = onf_split_kernel<NKT, NT, MODE>;
+  if (!attr_set) {
+    NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)L::BYTES));
+    attr_set = true;
+  }
+  u32x4* blob = nullptr;
+  int rc = blob_for_device(B::BYTES, &blob);
+  if (rc != NFOPP_OK) return rc;
+  // third weight level in consumption order (the parameters may have changed since the last call: always rebuilt)
+  hipLaunchKernelGGL(split_prep_kernel<NKT>, dim3(B::STEPS), dim3(64), 0, stream, a.geom, a.params, blob);
+  NFOPP_HIP(hipGetLastError());
+  constexpr int CH = WAVES * 16 * NT;
+  long long n_chunks = (a.n_points + CH - 1) / CH;
+  long long grid = query_cus();
+  if (grid > n_chunks) grid = n_chunks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), L::BYTES, stream, a, (const u32x4*)blob);
+  NFOPP_HIP(hipGetLastError());
+  return NFOPP_OK;
+}
+
+template <int MODE>
+static int launch_split_mode(const OnfKernelArgs& a, hipStream_t stream) {
+  const int nkt = (a.geom.fin + 15) / 16;
+  const bool small = a.n_points < (long long)query_cus() * WAVES * 16 * 2;
+  switch (nkt) {
+    case 14: return small ? launch_split_t<14, 1, MODE>(a, stream) : launch_split_t<14, 2, MODE>(a, stream);
+    case 13: return small ? launch_split_t<13, 1, MODE>(a, stream) : launch_split_t<13, 2, MODE>(a, stream);
+    case 8: return launch_split_t<8, 1, MODE>(a, stream);
+    case 7: return launch_split_t<7, 1, MODE>(a, stream);
+    default:
+      set_error("unsupported ONF feature dimension %d", a.geom.fin);
+      return NFOPP_ERR_ARG;
+  }
+}
+
+int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only) {
+  if (a.n_points <= 0) return NFOPP_OK;
+  return forward_only ? launch_split_mode<2>(a, stream) : launch_split_mode<0>(a, stream);
+}
+
+}  // namespace nfopp
+
+using namespace nfopp;
+
+extern "C" int nfopp_set_matrix_path(int32_t path) {
+  NFOPP_REQUIRE(path == 0 || path == 1, "matrix path must be 0 (fp32 MFMA) or 1 (bf16x3 split MFMA)");
+  g_split_mode = path;
+  return NFOPP_OK;
+}
+
+extern "C" int nfopp_get_matrix_path(void) { return onf_split_enabled() ? 1 : 0; }

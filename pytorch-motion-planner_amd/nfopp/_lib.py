@@ -53,6 +53,8 @@ _SIGNATURES = {
                                               _P, _P, _P]),
     "nfopp_path_select_best": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                               _P, _P, _P, _P, _P]),
+    "nfopp_set_matrix_path": (ctypes.c_int, [ctypes.c_int32]),
+    "nfopp_get_matrix_path": (ctypes.c_int, []),
     "nfopp_init_trajectories": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                _P, _P]),
     "nfopp_path_postprocess": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,

@@ -1,0 +1,123 @@
+"""GPU: the bf16x3 split-precision matrix path of the fused ONF kernel (csrc/onf_split.hip) against the fp32-MFMA
+path, the golden vectors of the reference and a float64 evaluation of the same network.
+
+The split is exact (x = hi + mid + lo) and keeps the six partial products above 2^-24, so the two paths may differ by
+accumulation-order rounding only: the gate between them is 3e-6 of the output scale, and BOTH must meet the
+reference-parity gates of test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+gc = pytest.importorskip("gpu_common")
+import nfopp  # noqa: E402
+from nfopp import _lib  # noqa: E402
+from oracle import nfopp_oracle as orc  # noqa: E402
+
+F32 = np.float32
+
+
+@pytest.fixture
+def split_path():
+    lib = _lib.load()
+    _lib.check(lib.nfopp_set_matrix_path(1))
+    assert lib.nfopp_get_matrix_path() == 1
+    yield lib
+    _lib.check(lib.nfopp_set_matrix_path(0))
+
+
+def _eval(onf, x, path):
+    lib = _lib.load()
+    _lib.check(lib.nfopp_set_matrix_path(path))
+    try:
+        out = onf.forward_with_grad(torch.tensor(np.ascontiguousarray(x, F32), device="cuda"))
+        logits = onf(torch.tensor(np.ascontiguousarray(x, F32), device="cuda"))
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), logits.cpu().numpy().reshape(-1)
+    finally:
+        _lib.check(lib.nfopp_set_matrix_path(0))
+
+
+def _forward64(params, cfg, x):
+    """float64 evaluation of the same network (weights are the fp32 parameters): the yardstick for both paths"""
+    p = orc.unpack_params(np.asarray(params, F32), cfg)
+    p = {k: (np.asarray(v, np.float64) if v is not None else None) for k, v in p.items()}
+    x = np.asarray(x, np.float64)
+    u = (x[:, :2] - cfg.mean) / cfg.sigma
+    e = u @ p["we"].T + (p["be"] if p["be"] is not None else 0.0)
+    feats = [np.sin(e[:, :100])]
+    if cfg.use_cos:
+        feats.append(np.cos(e[:, 100:]))
+    if cfg.angle_encoding:
+        z = (x[:, 2:3] + p["ang_b"][None]) * p["ang_f"][None]
+        feats += [np.sin(z[:, :cfg.angle_dim]), np.cos(z[:, cfg.angle_dim:])]
+    fin = np.concatenate(feats, 1)
+    h1 = np.maximum(fin @ p["w1"].T + p["b1"], 0)
+    h2 = np.maximum(h1 @ p["w2"].T + p["b2"], 0)
+    return np.concatenate([h2, fin], 1) @ p["w3"].reshape(-1) + p["b3"].reshape(-1)[0]
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_split_vs_fp32_path_and_reference(tag):
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z[tag + "_cfg"], z[tag + "_params"])
+    x = z[tag + "_x"]
+    d = x.shape[1]
+    for n in (len(x), 1, 17, 255, 4099, 70000):      # one tile per wave below ~65k points, two above
+        rng = np.random.default_rng(n)
+        xs = x if n == len(x) else x[rng.integers(0, len(x), n)]
+        o0, l0 = _eval(onf, xs, 0)
+        o1, l1 = _eval(onf, xs, 1)
+        assert gc.scaled_err(o1[:, 0], o0[:, 0]) < 3e-6, (tag, n)
+        assert gc.scaled_err(o1[:, 1:1 + d], o0[:, 1:1 + d]) < 3e-6, (tag, n)
+        assert gc.scaled_err(l1, l0) < 3e-6
+        assert np.array_equal(l1, o1[:, 0]) or gc.scaled_err(l1, o1[:, 0]) < 1e-6   # forward-only kernel = same logits
+        if d == 2:
+            assert np.all(o1[:, 3] == 0)
+    # reference parity gates (identical to test_gpu_parity.py) on the split path
+    o1, _ = _eval(onf, x, 1)
+    tol = 3e-5 if tag == "b" else 1e-5
+    assert gc.scaled_err(o1[:, 0], z[tag + "_logit"]) < tol
+    assert gc.scaled_err(o1[:, 1:1 + d], z[tag + "_grad"]) < 5 * tol
+
+
+def test_split_path_is_at_least_as_close_to_float64():
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z["a_cfg"], z["a_params"])
+    x = z["a_x"]
+    want = _forward64(z["a_params"], cfg, x)
+    o0, _ = _eval(onf, x, 0)
+    o1, _ = _eval(onf, x, 1)
+    e0, e1 = gc.scaled_err(o0[:, 0], want), gc.scaled_err(o1[:, 0], want)
+    # both carry the fp32 rounding of the encoding arguments (|arg| * 6e-8); the split path must not add to it
+    assert e1 < 1e-5 and e1 < 1.5 * e0 + 5e-7, (e0, e1)
+
+
+@pytest.mark.parametrize("name", ["traj_n100_default.npz", "traj_n256_default.npz"])
+def test_split_collision_eval_and_rollout(name, split_path):
+    zz = load_golden(name)
+    onf, cfg = gc.make_onf(zz["cfg"], zz["params"])
+    hp = orc.Hyper.from_npz(zz)
+    s = gc.state_of(zz, "s0_")
+    eng = gc.engine_from_state(onf, s, hp)
+    eng.collision_eval(zz["g2_t"][None])
+    torch.cuda.synchronize()
+    out = eng.onf_out.cpu().numpy()[0]
+    assert gc.scaled_err(out[:, 0], zz["g2_logit"]) < 1e-5
+    # a batch large enough for two tiles per wave, device Philox draws: both paths from the same state
+    B = 300
+    sb = gc.state_of(zz, "s0_", reps=B)
+    res = []
+    for path in (1, 0):
+        _lib.check(split_path.nfopp_set_matrix_path(path))
+        e = gc.engine_from_state(onf, sb, hp)
+        e.seed = 7
+        for _ in range(3):
+            e.optimize_trajectory()
+        torch.cuda.synchronize()
+        res.append(e.traj.cpu().numpy())
+    _lib.check(split_path.nfopp_set_matrix_path(1))
+    assert np.max(np.abs(res[0] - res[1])) < 2e-5
