@@ -80,7 +80,7 @@ struct Blob {
   static constexpr int L2T = L2 + HKB * HT;   // step = kb * HT + mt
   static constexpr int L1T = L2T + HKB * HT;  // step = mt * HKB + kb
   static constexpr int STEPS = L1T + NKT * HKB;
-  static constexpr size_t BYTES = size_t(STEPS) * 64 * 16;
+  static constexpr size_t BYTES = size_t(STEPS + 2) * 64 * 16;   // + the two-step look-ahead past the last step
 };
 
 struct LaneGeom {
@@ -147,9 +147,14 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 
   const OnfGeom& geo = a.geom;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, g = lane >> 4, gi = i >> 2, ri = i & 3;
-  const int colP = 16 * (g & 1) + 4 * (g >> 1), colQ = 8 * (g & 1) + 4 * (g >> 1);
-  const int rowposP = 16 * (gi & 1) + 4 * (gi >> 1) + ri, rowposQ = 8 * (gi & 1) + 4 * (gi >> 1) + ri;
+  const int i = lane & 15, g = lane >> 4, ri = i & 3;
+  int gi = i >> 2;
+  int colP = 16 * (g & 1) + 4 * (g >> 1), colQ = 8 * (g & 1) + 4 * (g >> 1);
+  int rowposP = 16 * (gi & 1) + 4 * (gi >> 1) + ri, rowposQ = 8 * (gi & 1) + 4 * (gi >> 1) + ri;
+  // Every LDS address below derives from these five lane constants.  Left to itself hipcc computes all ~40 addresses
+  // once, in front of the persistent loop, and spills them; an empty asm makes them opaque at the start of each GEMM so
+  // that they are re-derived (a few integer ops) where they are used.
+#define NFOPP_REDERIVE() asm volatile("" : "+v"(colP), "+v"(colQ), "+v"(rowposP), "+v"(rowposQ), "+v"(gi))
   const int first_angle_kb = geo.n_ang ? geo.n_enc / 32 : B::NKB;   // first k block that can hold an angle feature
 
   const float* W1 = lds + L::W1;
@@ -158,7 +163,11 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
   constexpr int CH = WAVES * 16 * NT;
   const long long n_chunks = (a.n_points + CH - 1) / CH;
   const float b3 = a.params[geo.off_b3];
-  const u32x4* lob = blob + lane;
+  // third-level fragments: uniform base + step (scalar registers) + 16 * lane (one vector register)
+  const unsigned lane16 = lane * 16;
+  auto lo_frag = [&](int step) __attribute__((always_inline)) {
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(blob) + (size_t)step * 1024 + lane16);
+  };
 
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // ---------------------------------------------------------------- sample / load the wave's points
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     }
 
     // ---------------------------------------------------------------- L1: a1 = W1 in + b1, features just-in-time
+    NFOPP_REDERIVE();
     f32x4 acc1[NT][HT];
     float skip[NT];
 #pragma unroll
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     const float* ftl = lds + L::FT + L::FTS * colP;
     const float* isl = lds + L::ISA + colP;
 
+    u32x4 q0 = lo_frag(B::L1), q1 = lo_frag(B::L1 + 1);   // third-level fragments of the next two steps
     auto l1_block = [&](auto ang_c, int kb) __attribute__((always_inline)) {
       constexpr bool ANG = decltype(ang_c)::value;
       const int off = 32 * kb;   // base_p(2 kb); the second tile of the pair sits 8 columns further
@@ -275,18 +286,16 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       const float* pa = w1a + off;
       const float* pb = w1b + off;
       const float* pc = w1c + off;
-      const u32x4* lo = lob + (B::L1 + kb * HT) * 64;
+      const int lo_step = B::L1 + kb * HT;
       // weight words of tile mt+1 are fetched while tile mt multiplies (the fences keep hipcc from hoisting every load
       // of the unrolled loop to the top, which spills)
       float wn[8];
-      u32x4 aln;
       auto fetch = [&](int mt) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = 8 * (j >> 2) + (j & 3);
           wn[j] = mt < 4 ? pa[mt * 16 * S1 + c] : (mt < 6 ? pb[(mt - 4) * 16 * S1 + c] : pc[c]);
         }
-        aln = lo[mt * 64];
       };
       fetch(0);
 #pragma unroll
@@ -294,7 +303,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         float w[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = wn[j];
-        const u32x4 al = aln;
+        const u32x4 al = q0;
+        q0 = q1;
+        q1 = lo_frag(lo_step + mt + 2);   // runs on into the next k block (and, at the end, into L2's first steps)
         if (mt + 1 < HT) fetch(mt + 1);
         __builtin_amdgcn_sched_barrier(0);
         u32x4 ah, am;
@@ -310,6 +321,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     for (int kb = first_angle_kb; kb < B::NKB; ++kb) l1_block(std::true_type{}, kb);
 
     // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
+    NFOPP_REDERIVE();
     f32x4 acc2[NT][HT];
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt) {
@@ -322,16 +334,15 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 #pragma unroll
       for (int mt = 0; mt < HT; ++mt) rowoff2[mt] = (mt < 6 ? base_p(mt) + rowposP : 96 + gi) * S2;
       float wn[8];
-      u32x4 aln;
       auto fetch = [&](int kb, int mt) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int t = 2 * kb + (j >> 2), r = j & 3;
           wn[j] = t < 6 ? W2[rowoff2[mt] + 16 * t + r + colQ] : ((t == 6 && r == 0) ? W2[rowoff2[mt] + 96 + g] : 0.0f);
         }
-        aln = lob[(B::L2 + kb * HT + mt) * 64];
       };
       fetch(0, 0);
+      u32x4 q0 = lo_frag(B::L2), q1 = lo_frag(B::L2 + 1);
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
         u32x4 bh[NT], bm[NT], bl[NT];
@@ -350,7 +361,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
           float w[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) w[j] = wn[j];
-          const u32x4 al = aln;
+          const u32x4 al = q0;
+          q0 = q1;
+          q1 = lo_frag(B::L2 + kb * HT + mt + 2);
           if (mt + 1 < HT) fetch(kb, mt + 1);
           else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
           __builtin_amdgcn_sched_barrier(0);
@@ -396,6 +409,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     }
 
     // ---------------------------------------------------------------- L2T: dh1 = (W2^T dh2) * [a1 > 0]
+    NFOPP_REDERIVE();
     {
       // the sign pattern of a1 is all L2T needs from it: 28 bits per point tile free its 28 registers
       unsigned mask1[NT];
@@ -416,7 +430,6 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 #pragma unroll
       for (int mt = 0; mt < HT; ++mt) coloff[mt] = mt < 6 ? 16 * mt + rowposQ : 96 + gi;
       float wn[8];
-      u32x4 aln;
       auto fetch = [&](int kb, int mt) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -424,9 +437,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
           wn[j] = t < 6 ? W2[(base_p(t) + r + colP) * S2 + coloff[mt]]
                         : ((t == 6 && r == 0) ? W2[(96 + g) * S2 + coloff[mt]] : 0.0f);
         }
-        aln = lob[(B::L2T + kb * HT + mt) * 64];
       };
       fetch(0, 0);
+      u32x4 q0 = lo_frag(B::L2T), q1 = lo_frag(B::L2T + 1);
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
         u32x4 bh[NT], bm[NT], bl[NT];
@@ -445,7 +458,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
           float w[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) w[j] = wn[j];
-          const u32x4 al = aln;
+          const u32x4 al = q0;
+          q0 = q1;
+          q1 = lo_frag(B::L2T + kb * HT + mt + 2);
           if (mt + 1 < HT) fetch(kb, mt + 1);
           else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
           __builtin_amdgcn_sched_barrier(0);
@@ -466,6 +481,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     }
 
     // ---------------------------------------------------------------- L1T: din = W1^T dh1 + W3b, then the chain rule
+    NFOPP_REDERIVE();
     float gx[NT], gy[NT], gt[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) gx[tl] = gy[tl] = gt[tl] = 0.f;
@@ -484,6 +500,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         split8(hv, dh[kb][tl], dm[kb][tl], dl[kb][tl]);
       }
     const int rowkQ = colQ * S1;
+    u32x4 q0t = lo_frag(B::L1T), q1t = lo_frag(B::L1T + 1);
 
     auto l1t_tile = [&](auto ang_c, int mt) __attribute__((always_inline)) {
       constexpr bool ANG = decltype(ang_c)::value;
@@ -493,16 +510,14 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       f32x4 acc[NT];
 #pragma unroll
       for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
-      const u32x4* lo = lob + (B::L1T + mt * B::HKB) * 64;
+      const int lo_step = B::L1T + mt * B::HKB;
       float wn[8];
-      u32x4 aln;
       auto fetch = [&](int kb) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int t = 2 * kb + (j >> 2), r = j & 3;
           wn[j] = t < 6 ? W1[rowkQ + (16 * t + r) * S1 + colA] : ((t == 6 && r == 0) ? W1[(96 + g) * S1 + colA] : 0.0f);
         }
-        aln = lo[kb * 64];
       };
       fetch(0);
 #pragma unroll
@@ -510,7 +525,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         float w[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = wn[j];
-        const u32x4 al = aln;
+        const u32x4 al = q0t;
+        q0t = q1t;
+        q1t = lo_frag(lo_step + kb + 2);
         if (kb + 1 < B::HKB) fetch(kb + 1);
         __builtin_amdgcn_sched_barrier(0);
         u32x4 ah, am;

@@ -1,0 +1,32 @@
+"""Dev tool: time the fused ONF kernel (trajectory mode, cfg3 shape) on the fp32-MFMA and the bf16x3 split path."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, "pytorch-motion-planner_amd")
+import nfopp
+from nfopp import _lib
+
+def main():
+    torch.manual_seed(0)
+    onf = nfopp.ONF(0.0, 10.0, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to("cuda")
+    B, N = 4096, 256
+    eng = nfopp.TrajectoryEngine(onf, B, N, 3, nfopp.TrajectoryHyper(bounds=(0, 100, 0, 100)), 0.5, "cuda")
+    eng.traj.copy_(torch.rand(B, N, 3, device="cuda") * 100)
+    lib = _lib.load()
+    outs = {}
+    for path in (0, 1, 0, 1):
+        _lib.check(lib.nfopp_set_matrix_path(path))
+        for _ in range(5):
+            eng.collision_eval()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            eng.collision_eval()
+        e1.record(); torch.cuda.synchronize()
+        outs[path] = eng.onf_out.clone()
+        print("path %d: %.3f ms per call" % (path, e0.elapsed_time(e1) / 20))
+    d = (outs[0] - outs[1]).abs().max().item()
+    print("max |fp32 - split| =", d, " scale", outs[0].abs().max().item())
+    _lib.check(lib.nfopp_set_matrix_path(0))
+
+main()
