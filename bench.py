@@ -35,6 +35,8 @@ import nfopp  # noqa: E402
 
 FLOP_PER_SAMPLE = 131400.0      # 65 700 FMA per collision sample (fwd 32 740 + input-bwd 32 960)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+SPLIT_PRODUCTS = 6              # bf16x3 split path: partial products issued per fp32 multiply (csrc/onf_split.hip)
 B_PER_GPU, N_WAYPOINTS = 4096, 256
 BOUNDS = (0.0, 100.0, 0.0, 100.0)
 
@@ -118,6 +120,24 @@ def pmc_traffic(batch, n):
         return None
 
 
+def roofline(matrix_path, achieved, k1_ms, samples, traffic):
+    """`achieved` is ALGORITHMIC fp32 FLOP/s of the fused ONF kernel in both cases.  fp32 path: against the fp32 MFMA
+    peak.  Split path: the kernel runs on the bf16 matrix pipe and issues 6 bf16 partial products per fp32 multiply,
+    so the peak that bounds it is the dense bf16 peak / 6 (fp32-equivalent); the fp32-MFMA ratio is given beside it."""
+    out = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": traffic, "kernel_ms": k1_ms,
+           "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE}
+    if matrix_path == "split":
+        peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+        out.update({"peak": peak, "frac": achieved / peak, "kernel": "onf_split_kernel<14,2,0>",
+                    "pipe": "bf16 MFMA 16x16x32, %d partial products per fp32 multiply (exact 3-level operand split)" % SPLIT_PRODUCTS,
+                    "pipe_peak": PEAK_BF16_MFMA_TFLOPS, "executed_tflops": achieved * SPLIT_PRODUCTS,
+                    "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS})
+    else:
+        out.update({"peak": PEAK_FP32_MFMA_TFLOPS, "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                    "kernel": "onf_fwd_bwd_kernel<14,2,0>"})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +150,11 @@ def main():
     ap.add_argument("--workload", choices=("cfg3", "cfg5"), default="cfg3",
                     help="cfg3 (default, the headline): 4096x256 frozen field.  cfg5: 4096x512 per GPU with continuous "
                          "ONF learning every step (device sampling + checker + MFMA fit + gradient all-reduce)")
+    ap.add_argument("--matrix-path", choices=("split", "fp32"), default="split",
+                    help="fused ONF kernel: bf16x3 split-precision MFMA (default, fp32-faithful) or fp32 MFMA")
     args = ap.parse_args()
+    from nfopp import _lib
+    _lib.check(_lib.load().nfopp_set_matrix_path(1 if args.matrix_path == "split" else 0))
     global N_WAYPOINTS
     if args.workload == "cfg5":
         N_WAYPOINTS = 512
@@ -219,12 +243,10 @@ def main():
                                     "all-reduce over ranks (last fit loss %.3f)"
                                     % (B, N, planner.sampler.B * planner.sampler.S, float(planner.fitter.last_loss))),
                        "trajectories_per_gpu": B, "waypoints": N, "global_batch": world * B,
-                       "parallelism": "trajectory shards, no data-path collective" if checker is None else "trajectory shards + one all-reduce of the 33163-float ONF gradient buffer per step", "paths_finite": finite,
+                       "parallelism": "trajectory shards, no data-path collective" if checker is None else "trajectory shards + one all-reduce of the 33163-float ONF gradient buffer per step", "paths_finite": finite, "matrix_path": args.matrix_path,
                        "planner_steps_per_s": args.steps / elapsed},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(B, N) if checker is None else None,
-                         "kernel": "onf_fwd_bwd_kernel<14,2>", "kernel_ms": k1_ms,
-                         "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE},
+            "roofline": roofline(args.matrix_path, achieved, k1_ms, samples,
+                                 pmc_traffic(B, N) if checker is None else None),
         }
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(onf.flat_parameters.cpu().numpy(), starts, goals,

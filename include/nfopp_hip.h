@@ -194,9 +194,11 @@ int nfopp_path_select_best(const float* labels_dev, const float* length_dev, con
                            int32_t poses_per_path, int32_t n_waypoints, int32_t dim, float* best_traj_dev,
                            float* best_length_dev, uint8_t* collides_dev, uint8_t* active_dev, void* stream);
 /* Matrix path of the fused ONF kernels (nfopp_onf_eval_points / _logits / nfopp_traj_collision_eval):
- *   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32), 1 = bf16x3 split-precision MFMA: every fp32 operand split exactly into three
- *   bf16 levels, six partial products per multiply accumulated in fp32 on the bf16 matrix pipe (fp32-faithful; see
- *   csrc/onf_split.hip).  The environment variable NFOPP_MATRIX_PATH=split selects 1 at load time.  Process-wide. */
+ *   1 (default) = bf16x3 split-precision MFMA: every fp32 operand is split EXACTLY into three bf16 levels and the six
+ *       partial products above 2^-24 are accumulated in fp32 on the bf16 matrix pipe (csrc/onf_split.hip) -- fp32-faithful
+ *       (closer to float64 than a sequential fp32 dot product), 1.33x faster than
+ *   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/onf_fused.hip), which the ONF training pass always uses.
+ *   The environment variable NFOPP_MATRIX_PATH=fp32 selects 0 at load time.  Process-wide. */
 int nfopp_set_matrix_path(int32_t path);
 int nfopp_get_matrix_path(void);
 

@@ -27,6 +27,13 @@
 
 namespace nfopp {
 
+// Fences between MFMA steps pin the MEMORY instructions of a step (so that hipcc does not hoist every load of the
+// unrolled loops to the top and spill) but let vector, scalar and matrix instructions cross, so that the packing and
+// splitting of the next step can be interleaved with the MFMAs of this one.
+#ifndef NFOPP_FENCE
+#define NFOPP_FENCE 0x40E   /* may cross: VALU 0x2 | SALU 0x4 | MFMA 0x8 | transcendental 0x400 */
+#endif
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -307,12 +314,12 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         q0 = q1;
         q1 = lo_frag(lo_step + mt + 2);   // runs on into the next k block (and, at the end, into L2's first steps)
         if (mt + 1 < HT) fetch(mt + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
         u32x4 ah, am;
         pack_words(w, ah, am);
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc1[tl][mt]);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
       }
     };
 #pragma unroll 1
@@ -366,12 +373,12 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
           q1 = lo_frag(B::L2 + kb * HT + mt + 2);
           if (mt + 1 < HT) fetch(kb, mt + 1);
           else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
           u32x4 ah, am;
           pack_words(w, ah, am);
 #pragma unroll
           for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc2[tl][mt]);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
         }
       }
     }
@@ -463,12 +470,12 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
           q1 = lo_frag(B::L2T + kb * HT + mt + 2);
           if (mt + 1 < HT) fetch(kb, mt + 1);
           else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
           u32x4 ah, am;
           pack_words(w, ah, am);
 #pragma unroll
           for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], accd[tl][mt]);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
         }
       }
 #pragma unroll
@@ -529,12 +536,12 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         q0t = q1t;
         q1t = lo_frag(lo_step + kb + 2);
         if (kb + 1 < B::HKB) fetch(kb + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
         u32x4 ah, am;
         pack_words(w, ah, am);
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma6(ah, am, al, dh[kb][tl], dm[kb][tl], dl[kb][tl], acc[tl]);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
       }
       const float* fte = lds + L::FT + L::FTS * fbase;
       if (NT == 2) {
@@ -590,12 +597,12 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-static int g_split_mode = -1;   // -1: read NFOPP_MATRIX_PATH on first use; 0: fp32 MFMA; 1: bf16x3 split
+static int g_split_mode = -1;   // -1: read NFOPP_MATRIX_PATH on first use; 0: fp32 MFMA; 1: bf16x3 split (default)
 
 bool onf_split_enabled() {
   if (g_split_mode < 0) {
     const char* e = getenv("NFOPP_MATRIX_PATH");
-    g_split_mode = (e && (e[0] == 's' || e[0] == 'b' || e[0] == '1')) ? 1 : 0;   // "split" / "bf16x3" / "1"
+    g_split_mode = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;   // "fp32" / "0" select the fp32 MFMA kernels
   }
   return g_split_mode == 1;
 }
