@@ -173,7 +173,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
   // third-level fragments: uniform base + step (scalar registers) + 16 * lane (one vector register)
   const unsigned lane16 = lane * 16;
   auto lo_frag = [&](int step) __attribute__((always_inline)) {
-    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(blob) + (size_t)step * 1024 + lane16);
+    const char* sb = reinterpret_cast<const char*>(blob) + (size_t)step * 1024;
+    asm("" : "+s"(sb));   // keep the step base in scalar registers (else: one 64-bit vector address per step, spilled)
+    return *reinterpret_cast<const u32x4*>(sb + lane16);
   };
 
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
