@@ -8,6 +8,6 @@ timeout -k 10 500 python bench.py --steps ${STEPS:-100} --warmup 10 > gpurun_out
 cat gpurun_out/bench.json
 export TMPDIR=/tmp
 R=$PWD
-cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --steps 30 --warmup 5 --cpu-sample 0 > $R/gpurun_out/prof_run.log 2>&1
+cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --steps 200 --warmup 20 --cpu-sample 0 --fit-iters 100 --spin-up 0 > $R/gpurun_out/prof_run.log 2>&1
 cd $R
 find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12

@@ -8,7 +8,7 @@ mkdir -p $R/gpurun_out/pmc_split
 cd /tmp
 run() {  # name, counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_split/$name -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-sample 0 --fit-iters 20 > $R/gpurun_out/pmc_split/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $R/gpurun_out/pmc_split/$name.log; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_split/$name -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-sample 0 --fit-iters 20 --spin-up 0 > $R/gpurun_out/pmc_split/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $R/gpurun_out/pmc_split/$name.log; }
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
