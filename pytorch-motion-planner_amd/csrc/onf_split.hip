@@ -67,6 +67,15 @@ __device__ __forceinline__ void split8(const float x[8], u32x4& hi, u32x4& mid, 
   }
 }
 
+// The last hidden k block holds only the four hidden units 96..99 (one per lane group): instead of six 32-deep bf16
+// products with 28 empty k slots it is issued as ONE fp32 MFMA 16x16x4 on the exact fp32 weight, rebuilt from its
+// (hi | mid) word and the third level of the blob fragment (hi + mid is exact in fp32, + lo gives the weight back).
+__device__ __forceinline__ float rebuild_weight(float word, unsigned lo_half) {
+  const unsigned w = __float_as_uint(word);
+  return (__uint_as_float(w & 0xffff0000u) + __uint_as_float(w << 16)) + __uint_as_float(lo_half << 16);
+}
+constexpr int TAIL_KB = 3;   // hidden k block issued on the fp32 matrix instruction
+
 // 8 (hi | mid) weight words -> the hi and the mid fragment
 __device__ __forceinline__ void pack_words(const float w[8], u32x4& hi, u32x4& mid) {
 #pragma unroll
@@ -355,8 +364,11 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
         u32x4 bh[NT], bm[NT], bl[NT];
+        float tail_b[NT];   // k block 3: the fp32 value of hidden unit 96 + g
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) {
+          tail_b[tl] = relu1(acc1[tl][6][0]);
+          if (kb == TAIL_KB) continue;
           float hv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -376,10 +388,16 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
           if (mt + 1 < HT) fetch(kb, mt + 1);
           else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
           __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
-          u32x4 ah, am;
-          pack_words(w, ah, am);
+          if (kb == TAIL_KB) {
+            const float wf = rebuild_weight(w[0], al[0] & 0xffffu);
 #pragma unroll
-          for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc2[tl][mt]);
+            for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma4(wf, tail_b[tl], acc2[tl][mt]);
+          } else {
+            u32x4 ah, am;
+            pack_words(w, ah, am);
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc2[tl][mt]);
+          }
           __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
         }
       }
@@ -452,8 +470,11 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
         u32x4 bh[NT], bm[NT], bl[NT];
+        float tail_b[NT];   // k block 3: the fp32 value of hidden unit 96 + g
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) {
+          tail_b[tl] = acc2[tl][6][0];
+          if (kb == TAIL_KB) continue;
           float hv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -473,10 +494,16 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
           if (mt + 1 < HT) fetch(kb, mt + 1);
           else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
           __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
-          u32x4 ah, am;
-          pack_words(w, ah, am);
+          if (kb == TAIL_KB) {
+            const float wf = rebuild_weight(w[0], al[0] & 0xffffu);
 #pragma unroll
-          for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], accd[tl][mt]);
+            for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma4(wf, tail_b[tl], accd[tl][mt]);
+          } else {
+            u32x4 ah, am;
+            pack_words(w, ah, am);
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], accd[tl][mt]);
+          }
           __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
         }
       }
@@ -495,9 +522,12 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) gx[tl] = gy[tl] = gt[tl] = 0.f;
     // dh1 in three levels, once for all output tiles: 4 k blocks x NT
-    u32x4 dh[B::HKB][NT], dm[B::HKB][NT], dl[B::HKB][NT];
+    u32x4 dh[TAIL_KB][NT], dm[TAIL_KB][NT], dl[TAIL_KB][NT];
+    float tail_d[NT];   // dh1 of hidden unit 96 + g (fp32 tail step)
 #pragma unroll
-    for (int kb = 0; kb < B::HKB; ++kb)
+    for (int tl = 0; tl < NT; ++tl) tail_d[tl] = acc1[tl][6][0];
+#pragma unroll
+    for (int kb = 0; kb < TAIL_KB; ++kb)
 #pragma unroll
       for (int tl = 0; tl < NT; ++tl) {
         float hv[8];
@@ -539,10 +569,17 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         q1t = lo_frag(lo_step + kb + 2);
         if (kb + 1 < B::HKB) fetch(kb + 1);
         __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
-        u32x4 ah, am;
-        pack_words(w, ah, am);
+        if (kb == TAIL_KB) {
+          const float wf = rebuild_weight(w[0], al[0] & 0xffffu);
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma6(ah, am, al, dh[kb][tl], dm[kb][tl], dl[kb][tl], acc[tl]);
+          for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma4(wf, tail_d[tl], acc[tl]);
+        } else {
+          u32x4 ah, am;
+          pack_words(w, ah, am);
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl)
+            acc[tl] = mfma6(ah, am, al, dh[kb < TAIL_KB ? kb : 0][tl], dm[kb < TAIL_KB ? kb : 0][tl], dl[kb < TAIL_KB ? kb : 0][tl], acc[tl]);
+        }
         __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
       }
       const float* fte = lds + L::FT + L::FTS * fbase;
