@@ -182,9 +182,13 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
   // third-level fragments: uniform base + step (scalar registers) + 16 * lane (one vector register)
   const unsigned lane16 = lane * 16;
   auto lo_frag = [&](int step) __attribute__((always_inline)) {
-    const char* sb = reinterpret_cast<const char*>(blob) + (size_t)step * 1024;
-    asm("" : "+s"(sb));   // keep the step base in scalar registers (else: one 64-bit vector address per step, spilled)
-    return *reinterpret_cast<const u32x4*>(sb + lane16);
+    // explicit global address space + a scalar step base: a generic pointer would become a FLAT load (which also counts
+    // against lgkmcnt, so every LDS wait would stall on the global latency), a vector base one 64-bit address per step
+    typedef const char __attribute__((address_space(1))) global_byte;
+    typedef const u32x4 __attribute__((address_space(1))) global_frag;
+    global_byte* sb = (global_byte*)blob + (size_t)step * 1024;
+    asm("" : "+s"(sb));
+    return *(global_frag*)(sb + lane16);
   };
 
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
