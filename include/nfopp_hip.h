@@ -196,7 +196,7 @@ int nfopp_path_select_best(const float* labels_dev, const float* length_dev, con
 /* Matrix path of the fused ONF kernels (nfopp_onf_eval_points / _logits / nfopp_traj_collision_eval):
  *   1 (default) = bf16x3 split-precision MFMA: every fp32 operand is split EXACTLY into three bf16 levels and the six
  *       partial products above 2^-24 are accumulated in fp32 on the bf16 matrix pipe (csrc/onf_split.hip) -- fp32-faithful
- *       (closer to float64 than a sequential fp32 dot product), 1.33x faster than
+ *       (closer to float64 than a sequential fp32 dot product), 1.5x faster than
  *   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/onf_fused.hip), which the ONF training pass always uses.
  *   The environment variable NFOPP_MATRIX_PATH=fp32 selects 0 at load time.  Process-wide. */
 int nfopp_set_matrix_path(int32_t path);
