@@ -198,7 +198,10 @@ int nfopp_path_select_best(const float* labels_dev, const float* length_dev, con
  *       partial products above 2^-24 are accumulated in fp32 on the bf16 matrix pipe (csrc/onf_split.hip) -- fp32-faithful
  *       (closer to float64 than a sequential fp32 dot product), 1.5x faster than
  *   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/onf_fused.hip), which the ONF training pass always uses.
- *   The environment variable NFOPP_MATRIX_PATH=fp32 selects 0 at load time.  Process-wide. */
+ *   The environment variable NFOPP_MATRIX_PATH=fp32 selects 0 at load time.  Process-wide.
+ *   Path 1 keeps ONE scratch buffer per device (the third weight level, 164 KB, rebuilt from params_dev by a 5 us
+ *   kernel in front of every evaluation on the caller's stream): evaluations of DIFFERENT parameter sets must not run
+ *   concurrently on different streams of one device. */
 int nfopp_set_matrix_path(int32_t path);
 int nfopp_get_matrix_path(void);
 
