@@ -13,6 +13,8 @@ __global__ __launch_bounds__(512) void k_coissue(float* out, int iters, float se
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
   b[0] += threadIdx.x;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 pk = {seed, seed};
   float v0 = seed, v1 = seed + 1, v2 = seed + 2, v3 = seed + 3, v4 = seed + 4, c = 1.0001f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -24,9 +26,14 @@ __global__ __launch_bounds__(512) void k_coissue(float* out, int iters, float se
       if (K == 3) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n v_fma_f32 %1, %1, %6, %1\n v_fma_f32 %2, %2, %6, %2\n v_fma_f32 %3, %3, %6, %3" : "+v"(acc[m & 3]), "+v"(v0), "+v"(v1), "+v"(v2) : "v"(a), "v"(b), "v"(c));
       if (K == 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n v_fma_f32 %1, %1, %7, %1\n v_fma_f32 %2, %2, %7, %2\n v_fma_f32 %3, %3, %7, %3\n v_fma_f32 %4, %4, %7, %4" : "+v"(acc[m & 3]), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(a), "v"(b), "v"(c));
       if (K == 5) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %6, %7, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %3, %3, %8, %3\n v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5" : "+v"(acc[m & 3]), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4) : "v"(a), "v"(b), "v"(c));
+      if (K == 6) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n v_perm_b32 %1, %1, %2, %5\n v_perm_b32 %2, %2, %1, %5" : "+v"(acc[m & 3]), "+v"(v0), "+v"(v1) : "v"(a), "v"(b), "s"(0x07060302));
+      if (K == 7) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n s_waitcnt lgkmcnt(7)\n v_perm_b32 %1, %1, %2, %5\n v_perm_b32 %2, %2, %1, %5" : "+v"(acc[m & 3]), "+v"(v0), "+v"(v1) : "v"(a), "v"(b), "s"(0x07060302));
+      if (K == 8) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n v_and_b32 %1, 0xffff0000, %1\n v_sub_f32 %2, %2, %1" : "+v"(acc[m & 3]), "+v"(v0), "+v"(v1) : "v"(a), "v"(b));
+      if (K == 9) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_pk_fma_f32 %1, %1, %1, %1" : "+v"(acc[m & 3]), "+v"(pk) : "v"(a), "v"(b), "v"(c));
+      if (K == 10) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n v_sin_f32 %1, %1\n v_fma_f32 %2, %2, %5, %2" : "+v"(acc[m & 3]), "+v"(v0), "+v"(v1) : "v"(a), "v"(b), "v"(c));
     }
   }
-  float s = v0 + v1 + v2 + v3 + v4;
+  float s = v0 + v1 + v2 + v3 + v4 + pk.x + pk.y;
   for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
@@ -58,6 +65,8 @@ int main() {
     printf("%d waves per SIMD:\n", threads / 256);
     run<0>(out, threads); run<1>(out, threads); run<2>(out, threads); run<3>(out, threads);
     run<4>(out, threads); run<5>(out, threads);
+    printf("  (6: 2 v_perm  7: s_waitcnt + 2 v_perm  8: v_and + v_sub  9: 1 v_pk_fma_f32  10: v_sin + v_fma)\n");
+    run<6>(out, threads); run<7>(out, threads); run<8>(out, threads); run<9>(out, threads); run<10>(out, threads);
   }
   return 0;
 }
