@@ -86,6 +86,28 @@ __device__ __forceinline__ void pack_words(const float w[8], u32x4& hi, u32x4& m
   }
 }
 
+// One MFMA step (6 partial products per point tile) with the 8 packing permutes of the NEXT step placed between the
+// MFMAs -- two behind every third MFMA (NT = 2) -- and a full scheduling fence after each MFMA so that hipcc keeps this
+// order: behind a v_mfma_f32_16x16x32_bf16 two simple vector instructions issue for free (tools/micro/
+// mfma_valu_coissue.hip).  ACC_(tl) names the accumulator of point tile tl; WN_ are the raw (hi | mid) words of the next
+// step, AHN_/AMN_ receive its packed fragments.
+#define NFOPP_STEP(ACC_, BH_, BM_, BL_, AH_, AM_, AL_, PACK_, WN_, AHN_, AMN_)                                \
+  _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {                                                          \
+    _Pragma("unroll") for (int tl_ = 0; tl_ < NT; ++tl_) {                                                     \
+      const u32x4 a_ = k_ == 0 ? AL_ : ((k_ == 2 || k_ == 3) ? AM_ : AH_);                                     \
+      const u32x4 b_ = k_ == 1 ? BL_[tl_] : ((k_ == 2 || k_ == 4) ? BM_[tl_] : BH_[tl_]);                      \
+      ACC_(tl_) = mfmab(a_, b_, ACC_(tl_));                                                                    \
+      const int q_ = k_ * NT + tl_;                                                                            \
+      const int p_ = NT == 2 ? (q_ % 3 == 1 ? q_ / 3 : -1) : (q_ == 0 || q_ == 1 ? q_ : (q_ == 3 || q_ == 4 ? q_ - 1 : -1)); \
+      if ((PACK_) && p_ >= 0 && p_ < 4) {                                                                      \
+        const unsigned x_ = __float_as_uint(WN_[2 * p_]), y_ = __float_as_uint(WN_[2 * p_ + 1]);              \
+        AHN_[p_] = __builtin_amdgcn_perm(y_, x_, 0x07060302);                                                  \
+        AMN_[p_] = __builtin_amdgcn_perm(y_, x_, 0x05040100);                                                  \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  }
+
 // ---- third-level blob: [gemm][step][lane] 16 bytes --------------------------------------------------------------
 template <int NKT>
 struct Blob {
@@ -260,6 +282,23 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     const float* isl = lds + L::ISA + colP;
 
     u32x4 q0 = lo_frag(B::L1), q1 = lo_frag(B::L1 + 1);   // third-level fragments of the next two steps
+    // raw (hi | mid) words: wa1 = the NEXT step (packed between this step's MFMAs), wb1 = the step after (in flight);
+    // ah1 / am1 = the packed fragments of the CURRENT step.  Steps run on over the k-block boundary.
+    float wa1[8], wb1[8];
+    u32x4 ah1, am1, ahn1 = {0, 0, 0, 0}, amn1 = {0, 0, 0, 0};
+    auto fetch1 = [&](int kb, int mt, float (&dst)[8]) __attribute__((always_inline)) {
+      const float* pa = w1a + 32 * kb;
+      const float* pb = w1b + 32 * kb;
+      const float* pc = w1c + 32 * kb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 8 * (j >> 2) + (j & 3);
+        dst[j] = mt < 4 ? pa[mt * 16 * S1 + c] : (mt < 6 ? pb[(mt - 4) * 16 * S1 + c] : pc[c]);
+      }
+    };
+    fetch1(0, 0, wa1);
+    pack_words(wa1, ah1, am1);
+    fetch1(0, 1, wa1);
     auto l1_block = [&](auto ang_c, int kb) __attribute__((always_inline)) {
       constexpr bool ANG = decltype(ang_c)::value;
       const int off = 32 * kb;   // base_p(2 kb); the second tile of the pair sits 8 columns further
@@ -305,36 +344,21 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) split8(fv[tl], bh[tl], bm[tl], bl[tl]);
       }
-      const float* pa = w1a + off;
-      const float* pb = w1b + off;
-      const float* pc = w1c + off;
       const int lo_step = B::L1 + kb * HT;
-      // weight words of tile mt+1 are fetched while tile mt multiplies (the fences keep hipcc from hoisting every load
-      // of the unrolled loop to the top, which spills)
-      float wn[8];
-      auto fetch = [&](int mt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = 8 * (j >> 2) + (j & 3);
-          wn[j] = mt < 4 ? pa[mt * 16 * S1 + c] : (mt < 6 ? pb[(mt - 4) * 16 * S1 + c] : pc[c]);
-        }
-      };
-      fetch(0);
 #pragma unroll
       for (int mt = 0; mt < HT; ++mt) {
-        float w[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = wn[j];
         const u32x4 al = q0;
         q0 = q1;
         q1 = lo_frag(lo_step + mt + 2);   // runs on into the next k block (and, at the end, into L2's first steps)
-        if (mt + 1 < HT) fetch(mt + 1);
-        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
-        u32x4 ah, am;
-        pack_words(w, ah, am);
+        fetch1(mt + 2 < HT ? kb : kb + 1, (mt + 2) % HT, wb1);   // past the last block: a harmless in-image read
+        __builtin_amdgcn_sched_barrier(0);
+#define NFOPP_ACC(tl) acc1[tl][mt]
+        NFOPP_STEP(NFOPP_ACC, bh, bm, bl, ah1, am1, al, true, wa1, ahn1, amn1)
+#undef NFOPP_ACC
+        ah1 = ahn1; am1 = amn1;
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc1[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc1[tl][mt]);
-        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
+        for (int j = 0; j < 8; ++j) wa1[j] = wb1[j];
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
 #pragma unroll 1
@@ -355,15 +379,21 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       int rowoff2[HT];  // rows in h2 layout P
 #pragma unroll
       for (int mt = 0; mt < HT; ++mt) rowoff2[mt] = (mt < 6 ? base_p(mt) + rowposP : 96 + gi) * S2;
-      float wn[8];
-      auto fetch = [&](int kb, int mt) __attribute__((always_inline)) {
+      // raw (hi | mid) words: wa = the NEXT step (packed between this step's MFMAs), wb = the step after (in flight)
+      float wa[8], wb[8];
+      auto fetch = [&](int kb, int mt, float (&dst)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int t = 2 * kb + (j >> 2), r = j & 3;
-          wn[j] = t < 6 ? W2[rowoff2[mt] + 16 * t + r + colQ] : ((t == 6 && r == 0) ? W2[rowoff2[mt] + 96 + g] : 0.0f);
+          dst[j] = t < 6 ? W2[rowoff2[mt] + 16 * t + r + colQ] : ((t == 6 && r == 0) ? W2[rowoff2[mt] + 96 + g] : 0.0f);
         }
       };
-      fetch(0, 0);
+      constexpr int NSTEP = B::HKB * HT;
+      u32x4 ah, am, ahn = {0, 0, 0, 0}, amn = {0, 0, 0, 0};
+      fetch(0, 0, wa);
+      pack_words(wa, ah, am);
+      float raw0 = wa[0];
+      fetch(0, 1, wa);
       u32x4 q0 = lo_frag(B::L2), q1 = lo_frag(B::L2 + 1);
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
@@ -383,26 +413,26 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         }
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) {
-          float w[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = wn[j];
+          const int st = kb * HT + mt;
           const u32x4 al = q0;
           q0 = q1;
-          q1 = lo_frag(B::L2 + kb * HT + mt + 2);
-          if (mt + 1 < HT) fetch(kb, mt + 1);
-          else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
-          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
+          q1 = lo_frag(B::L2 + st + 2);
+          if (st + 2 < NSTEP) fetch((st + 2) / HT, (st + 2) % HT, wb);
+          __builtin_amdgcn_sched_barrier(0);
           if (kb == TAIL_KB) {
-            const float wf = rebuild_weight(w[0], al[0] & 0xffffu);
+            const float wf = rebuild_weight(raw0, al[0] & 0xffffu);
 #pragma unroll
             for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma4(wf, tail_b[tl], acc2[tl][mt]);
           } else {
-            u32x4 ah, am;
-            pack_words(w, ah, am);
-#pragma unroll
-            for (int tl = 0; tl < NT; ++tl) acc2[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], acc2[tl][mt]);
+            const bool next_split = st + 1 < NSTEP && (st + 1) / HT < TAIL_KB;
+#define NFOPP_ACC(tl) acc2[tl][mt]
+            NFOPP_STEP(NFOPP_ACC, bh, bm, bl, ah, am, al, next_split, wa, ahn, amn)
+#undef NFOPP_ACC
           }
-          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
+          ah = ahn; am = amn; raw0 = wa[0];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wa[j] = wb[j];
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -460,16 +490,22 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       int coloff[HT];  // output rows = h1 layout Q -> column of W2
 #pragma unroll
       for (int mt = 0; mt < HT; ++mt) coloff[mt] = mt < 6 ? 16 * mt + rowposQ : 96 + gi;
-      float wn[8];
-      auto fetch = [&](int kb, int mt) __attribute__((always_inline)) {
+      // raw (hi | mid) words: wa = the NEXT step (packed between this step's MFMAs), wb = the step after (in flight)
+      float wa[8], wb[8];
+      auto fetch = [&](int kb, int mt, float (&dst)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int t = 2 * kb + (j >> 2), r = j & 3;
-          wn[j] = t < 6 ? W2[(base_p(t) + r + colP) * S2 + coloff[mt]]
+          dst[j] = t < 6 ? W2[(base_p(t) + r + colP) * S2 + coloff[mt]]
                         : ((t == 6 && r == 0) ? W2[(96 + g) * S2 + coloff[mt]] : 0.0f);
         }
       };
-      fetch(0, 0);
+      constexpr int NSTEP = B::HKB * HT;
+      u32x4 ah, am, ahn = {0, 0, 0, 0}, amn = {0, 0, 0, 0};
+      fetch(0, 0, wa);
+      pack_words(wa, ah, am);
+      float raw0 = wa[0];
+      fetch(0, 1, wa);
       u32x4 q0 = lo_frag(B::L2T), q1 = lo_frag(B::L2T + 1);
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
@@ -489,26 +525,26 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         }
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) {
-          float w[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = wn[j];
+          const int st = kb * HT + mt;
           const u32x4 al = q0;
           q0 = q1;
-          q1 = lo_frag(B::L2T + kb * HT + mt + 2);
-          if (mt + 1 < HT) fetch(kb, mt + 1);
-          else if (kb + 1 < B::HKB) fetch(kb + 1, 0);
-          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
+          q1 = lo_frag(B::L2T + st + 2);
+          if (st + 2 < NSTEP) fetch((st + 2) / HT, (st + 2) % HT, wb);
+          __builtin_amdgcn_sched_barrier(0);
           if (kb == TAIL_KB) {
-            const float wf = rebuild_weight(w[0], al[0] & 0xffffu);
+            const float wf = rebuild_weight(raw0, al[0] & 0xffffu);
 #pragma unroll
             for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma4(wf, tail_b[tl], accd[tl][mt]);
           } else {
-            u32x4 ah, am;
-            pack_words(w, ah, am);
-#pragma unroll
-            for (int tl = 0; tl < NT; ++tl) accd[tl][mt] = mfma6(ah, am, al, bh[tl], bm[tl], bl[tl], accd[tl][mt]);
+            const bool next_split = st + 1 < NSTEP && (st + 1) / HT < TAIL_KB;
+#define NFOPP_ACC(tl) accd[tl][mt]
+            NFOPP_STEP(NFOPP_ACC, bh, bm, bl, ah, am, al, next_split, wa, ahn, amn)
+#undef NFOPP_ACC
           }
-          __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
+          ah = ahn; am = amn; raw0 = wa[0];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wa[j] = wb[j];
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
@@ -545,46 +581,51 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     const int rowkQ = colQ * S1;
     u32x4 q0t = lo_frag(B::L1T), q1t = lo_frag(B::L1T + 1);
 
+    // step state of L1T (as in L1): steps run on from one output tile to the next
+    float wat[8], wbt[8], raw0t;
+    u32x4 aht, amt, ahnt = {0, 0, 0, 0}, amnt = {0, 0, 0, 0};
+    auto fetcht = [&](int mt, int kb, float (&dst)[8]) __attribute__((always_inline)) {
+      const int colA = base_p(mt) + rowposP;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 2 * kb + (j >> 2), r = j & 3;
+        dst[j] = t < 6 ? W1[rowkQ + (16 * t + r) * S1 + colA] : ((t == 6 && r == 0) ? W1[(96 + g) * S1 + colA] : 0.0f);
+      }
+    };
+    fetcht(0, 0, wat);
+    pack_words(wat, aht, amt);
+    raw0t = wat[0];
+    fetcht(0, 1, wat);
     auto l1t_tile = [&](auto ang_c, int mt) __attribute__((always_inline)) {
       constexpr bool ANG = decltype(ang_c)::value;
       const int fbase = base_p(mt) + colP;
-      const int colA = base_p(mt) + rowposP;
       const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
       f32x4 acc[NT];
 #pragma unroll
       for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
       const int lo_step = B::L1T + mt * B::HKB;
-      float wn[8];
-      auto fetch = [&](int kb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int t = 2 * kb + (j >> 2), r = j & 3;
-          wn[j] = t < 6 ? W1[rowkQ + (16 * t + r) * S1 + colA] : ((t == 6 && r == 0) ? W1[(96 + g) * S1 + colA] : 0.0f);
-        }
-      };
-      fetch(0);
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
-        float w[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = wn[j];
         const u32x4 al = q0t;
         q0t = q1t;
         q1t = lo_frag(lo_step + kb + 2);
-        if (kb + 1 < B::HKB) fetch(kb + 1);
-        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
+        fetcht(kb + 2 < B::HKB ? mt : mt + 1, (kb + 2) % B::HKB, wbt);   // past the last tile: a harmless in-image read
+        __builtin_amdgcn_sched_barrier(0);
         if (kb == TAIL_KB) {
-          const float wf = rebuild_weight(w[0], al[0] & 0xffffu);
+          const float wf = rebuild_weight(raw0t, al[0] & 0xffffu);
 #pragma unroll
           for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma4(wf, tail_d[tl], acc[tl]);
+          pack_words(wat, ahnt, amnt);   // next step: k block 0 of the next output tile
         } else {
-          u32x4 ah, am;
-          pack_words(w, ah, am);
-#pragma unroll
-          for (int tl = 0; tl < NT; ++tl)
-            acc[tl] = mfma6(ah, am, al, dh[kb < TAIL_KB ? kb : 0][tl], dm[kb < TAIL_KB ? kb : 0][tl], dl[kb < TAIL_KB ? kb : 0][tl], acc[tl]);
+#define NFOPP_ACC(tl) acc[tl]
+          NFOPP_STEP(NFOPP_ACC, dh[kb < TAIL_KB ? kb : 0], dm[kb < TAIL_KB ? kb : 0], dl[kb < TAIL_KB ? kb : 0], aht, amt, al,
+                     kb + 1 < TAIL_KB, wat, ahnt, amnt)
+#undef NFOPP_ACC
         }
-        __builtin_amdgcn_sched_barrier(NFOPP_FENCE);
+        aht = ahnt; amt = amnt; raw0t = wat[0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wat[j] = wbt[j];
+        __builtin_amdgcn_sched_barrier(0);
       }
       const float* fte = lds + L::FT + L::FTS * fbase;
       if (NT == 2) {
