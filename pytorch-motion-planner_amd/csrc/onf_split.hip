@@ -201,16 +201,14 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
   constexpr int CH = WAVES * 16 * NT;
   const long long n_chunks = (a.n_points + CH - 1) / CH;
   const float b3 = a.params[geo.off_b3];
-  // third-level fragments: uniform base + step (scalar registers) + 16 * lane (one vector register)
+  // third-level fragments through a buffer resource: address = base (4 scalar registers, built once) + 16 * lane (ONE
+  // vector register for the whole kernel) + the step's byte offset (a scalar operand) -- no per-step 64-bit vector
+  // address, no FLAT load (which would count against lgkmcnt and stall every LDS wait on the global latency)
   const unsigned lane16 = lane * 16;
+  const __amdgpu_buffer_rsrc_t blob_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(blob), 0, (int)B::BYTES, 0x00020000);
   auto lo_frag = [&](int step) __attribute__((always_inline)) {
-    // explicit global address space + a scalar step base: a generic pointer would become a FLAT load (which also counts
-    // against lgkmcnt, so every LDS wait would stall on the global latency), a vector base one 64-bit address per step
-    typedef const char __attribute__((address_space(1))) global_byte;
-    typedef const u32x4 __attribute__((address_space(1))) global_frag;
-    global_byte* sb = (global_byte*)blob + (size_t)step * 1024;
-    asm("" : "+s"(sb));
-    return *(global_frag*)(sb + lane16);
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane16, step * 1024, 0));
   };
 
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
