@@ -42,6 +42,20 @@ def test_param_count_and_argument_errors_without_gpu():
     assert rc == -1 and b"null" in lib.nfopp_last_error()
     rc = lib.nfopp_reparametrize(1, 10, 4, None, None, None, None, None, None, None, None)
     assert rc == -1
+    # the neighbours of the step and the matrix-path switch (ABI 3)
+    assert lib.nfopp_path_postprocess(None, 1, 2, 0.001, 0.05, 0, None, None, None) == -1     # < 3 poses
+    assert b"3..1026" in lib.nfopp_last_error()
+    assert lib.nfopp_path_postprocess(None, 1, 2000, 0.001, 0.05, 0, None, None, None) == -1  # > 1026 poses
+    assert lib.nfopp_path_postprocess(None, 1, 10, 0.001, 0.0, 0, None, None, None) == -1     # zero step
+    assert lib.nfopp_path_postprocess(None, 0, 10, 0.001, 0.05, 0, None, None, None) == 0     # empty batch: no-op
+    assert lib.nfopp_init_trajectories(None, None, 1, 10, 2, 1, None, None) == -1             # headings need dim 3
+    assert lib.nfopp_init_trajectories(None, None, 0, 10, 3, 0, None, None) == 0
+    assert lib.nfopp_set_matrix_path(2) == -1 and b"matrix path" in lib.nfopp_last_error()
+    before = lib.nfopp_get_matrix_path()
+    assert before in (0, 1)
+    assert lib.nfopp_set_matrix_path(0) == 0 and lib.nfopp_get_matrix_path() == 0
+    assert lib.nfopp_set_matrix_path(1) == 0 and lib.nfopp_get_matrix_path() == 1
+    assert lib.nfopp_set_matrix_path(before) == 0
 
 
 def test_product_path_fails_loudly_without_gpu():
