@@ -91,7 +91,11 @@ __device__ __forceinline__ void pack_words(const float w[8], u32x4& hi, u32x4& m
 // order: behind a v_mfma_f32_16x16x32_bf16 two simple vector instructions issue for free (tools/micro/
 // mfma_valu_coissue.hip).  ACC_(tl) names the accumulator of point tile tl; WN_ are the raw (hi | mid) words of the next
 // step, AHN_/AMN_ receive its packed fragments.
-#define NFOPP_STEP(ACC_, BH_, BM_, BL_, AH_, AM_, AL_, PACK_, WN_, AHN_, AMN_)                                \
+#define NFOPP_NOWORK(q_)
+#define NFOPP_STEP(ACC_, BH_, BM_, BL_, AH_, AM_, AL_, PACK_, WN_, AHN_, AMN_) \
+  NFOPP_STEP_W(ACC_, BH_, BM_, BL_, AH_, AM_, AL_, PACK_, WN_, AHN_, AMN_, NFOPP_NOWORK)
+// ... and WORK_(q) behind MFMA number q of the step (q = 0 .. 6 NT - 1) when that slot carries no permutes
+#define NFOPP_STEP_W(ACC_, BH_, BM_, BL_, AH_, AM_, AL_, PACK_, WN_, AHN_, AMN_, WORK_)                       \
   _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {                                                          \
     _Pragma("unroll") for (int tl_ = 0; tl_ < NT; ++tl_) {                                                     \
       const u32x4 a_ = k_ == 0 ? AL_ : ((k_ == 2 || k_ == 3) ? AM_ : AH_);                                     \
@@ -104,6 +108,7 @@ __device__ __forceinline__ void pack_words(const float w[8], u32x4& hi, u32x4& m
         AHN_[p_] = __builtin_amdgcn_perm(y_, x_, 0x07060302);                                                  \
         AMN_[p_] = __builtin_amdgcn_perm(y_, x_, 0x05040100);                                                  \
       }                                                                                                        \
+      if (p_ < 0) { WORK_(q_) }                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
   }
@@ -359,10 +364,127 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    if constexpr (NT == 2 && B::NKB == 7) {
+      // F = 200..224 at two tiles per wave: the features of block kb+1 (blocks 1..5: no angle features) are evaluated
+      // and split IN THE MFMA SHADOWS of block kb -- one evaluation and one pair-split in flight at a time, cut into
+      // single instructions and dealt five to a slot behind the MFMAs that carry no packing permutes (work item w of
+      // 232: items 0..143 = evaluation w/9 (feature j = e>>1 of point tile e&1), step w%9; items 144..231 = split of
+      // pair (w-144)/11, step (w-144)%11).  Same arithmetic, same order as l1_block's up-front evaluation.
+      u32x4 bhc[NT], bmc[NT], blc[NT], bhn[NT], bmn[NT], bln[NT];
+      float fvn[NT][8];
+      float e_arg = 0.f, e_j = 0.f, e_r = 0.f, e_t = 0.f, e_v = 0.f;
+      float s_ra = 0.f, s_rb = 0.f, s_la = 0.f, s_lb = 0.f;
+      unsigned s_ta = 0, s_tb = 0;
+      f32x4 tw[2], tq[2];   // table entry of feature j (ping-pong on j & 1): (wx wx wy wy), (qh qh w3 w3)
+      float tb[2];          // its bias
+      int nxt_off = 0;      // 32 (kb + 1): feature offset of the block being prepared
+      auto table_load = [&](int j) __attribute__((always_inline)) {
+        const float* e = ftl + L::FTS * (nxt_off + 8 * (j >> 2) + (j & 3));
+        tw[j & 1] = *reinterpret_cast<const f32x4*>(e);
+        tb[j & 1] = e[4];
+        tq[j & 1] = *reinterpret_cast<const f32x4*>(e + 8);
+      };
+      auto work_item = [&](int w) __attribute__((always_inline)) {
+        if (w < 144) {
+          const int e = w / 9, u = w % 9, j = e >> 1, tl = e & 1, b = j & 1;
+          if (u == 0) {
+            e_arg = fmaf(tw[b].z, uy[tl], tb[b]);
+            if (tl == 0 && j + 1 < 8) table_load(j + 1);
+          }
+          if (u == 1) e_arg = fmaf(tw[b].x, ux[tl], e_arg);
+          if (u == 2) e_t = fmaf(e_arg, 0.159154943f, 12582912.0f);
+          if (u == 3) e_j = e_t - 12582912.0f;
+          if (u == 4) e_r = fmaf(e_j, -6.28318548202514648f, e_arg);
+          if (u == 5) e_r = fmaf(e_j, 1.74845553e-07f, e_r);
+          if (u == 6) e_t = fmaf(e_r, 0.159154943f, tq[b].x);
+          if (u == 7) e_v = __builtin_amdgcn_sinf(e_t);
+          if (u == 8) { skip[tl] = fmaf(tq[b].z, e_v, skip[tl]); fvn[tl][j] = e_v; }
+        } else if (w < 232) {
+          const int sp = (w - 144) / 11, v = (w - 144) % 11, tl = sp >> 2, pp = sp & 3;
+          const float x0 = fvn[tl][2 * pp], x1 = fvn[tl][2 * pp + 1];
+          if (v == 0) bhn[tl][pp] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302);
+          if (v == 1) s_ta = __float_as_uint(x0) & 0xffff0000u;
+          if (v == 2) s_tb = __float_as_uint(x1) & 0xffff0000u;
+          if (v == 3) s_ra = x0 - __uint_as_float(s_ta);
+          if (v == 4) s_rb = x1 - __uint_as_float(s_tb);
+          if (v == 5) bmn[tl][pp] = __builtin_amdgcn_perm(__float_as_uint(s_rb), __float_as_uint(s_ra), 0x07060302);
+          if (v == 6) s_ta = __float_as_uint(s_ra) & 0xffff0000u;
+          if (v == 7) s_tb = __float_as_uint(s_rb) & 0xffff0000u;
+          if (v == 8) s_la = s_ra - __uint_as_float(s_ta);
+          if (v == 9) s_lb = s_rb - __uint_as_float(s_tb);
+          if (v == 10) bln[tl][pp] = __builtin_amdgcn_perm(__float_as_uint(s_lb), __float_as_uint(s_la), 0x07060302);
+        }
+      };
+      // MFMA steps of block kb on the fragments in bhc/bmc/blc; HOOK: prepare block kb + 1 behind them
+      auto l1_steps = [&](auto hook_c, int kb) __attribute__((always_inline)) {
+        constexpr bool HOOK = decltype(hook_c)::value;
+        const int lo_step = B::L1 + kb * HT;
+        if (HOOK) { nxt_off = 32 * (kb + 1); table_load(0); }
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          const u32x4 al = q0;
+          q0 = q1;
+          q1 = lo_frag(lo_step + mt + 2);
+          fetch1(mt + 2 < HT ? kb : kb + 1, (mt + 2) % HT, wb1);
+          __builtin_amdgcn_sched_barrier(0);
+#define NFOPP_ACC(tl) acc1[tl][mt]
+#define NFOPP_L1_WORK(q_)                                                                     \
+          if (HOOK) {                                                                          \
+            const int slot_ = mt * 8 + (q_) - ((q_) + 2) / 3;                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) work_item(5 * slot_ + i_);       \
+          }
+          NFOPP_STEP_W(NFOPP_ACC, bhc, bmc, blc, ah1, am1, al, true, wa1, ahn1, amn1, NFOPP_L1_WORK)
+#undef NFOPP_L1_WORK
+#undef NFOPP_ACC
+          ah1 = ahn1; am1 = amn1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wa1[j] = wb1[j];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto upfront = [&](auto ang_c, int kb) __attribute__((always_inline)) {   // l1_block's evaluation, no steps
+        constexpr bool ANG = decltype(ang_c)::value;
+        const int off = 32 * kb;
+        float fv[NT][8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float* fte = ftl + L::FTS * (off + 8 * half);
+          const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
+          f32x2 sk = {skip[0], skip[NT - 1]};
+          f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};
+          if (ANG) isa4 = *reinterpret_cast<const f32x4*>(isl + off + 8 * half);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r);
+            const f32x4 e1 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 4);
+            const f32x4 e2 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 8);
+            const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
+            const f32x2 qh = {e2.x, e2.y}, w3 = {e2.z, e2.w};
+            const f32x2 v = features2<ANG, false>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
+            sk = fma2(w3, v, sk);
+            fv[0][4 * half + r] = v.x; fv[NT - 1][4 * half + r] = v.y;
+          }
+          skip[0] = sk.x; skip[NT - 1] = sk.y;
+        }
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) split8(fv[tl], bhc[tl], bmc[tl], blc[tl]);
+      };
+      upfront(std::false_type{}, 0);
 #pragma unroll 1
-    for (int kb = 0; kb < first_angle_kb; ++kb) l1_block(std::false_type{}, kb);
+      for (int kb = 0; kb < 5; ++kb) {
+        l1_steps(std::true_type{}, kb);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) { bhc[tl] = bhn[tl]; bmc[tl] = bmn[tl]; blc[tl] = bln[tl]; }
+      }
+      l1_steps(std::false_type{}, 5);
+      upfront(std::true_type{}, 6);
+      l1_steps(std::false_type{}, 6);
+    } else {
 #pragma unroll 1
-    for (int kb = first_angle_kb; kb < B::NKB; ++kb) l1_block(std::true_type{}, kb);
+      for (int kb = 0; kb < first_angle_kb; ++kb) l1_block(std::false_type{}, kb);
+#pragma unroll 1
+      for (int kb = first_angle_kb; kb < B::NKB; ++kb) l1_block(std::true_type{}, kb);
+    }
 
     // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
     NFOPP_REDERIVE();
