@@ -783,10 +783,122 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       }
     };
     const int first_angle_kt = 2 * first_angle_kb < NKT ? 2 * first_angle_kb : NKT;
+    if constexpr (NT == 2 && B::NKB == 7) {
+      // As in L1: the chain-rule epilogue of output tile mt-1 (tiles without angle features) runs in the MFMA shadows of
+      // tile mt's steps.  92 work items per tile: evaluation e = w / 11 (feature row r = e >> 1 of point tile e & 1),
+      // step w % 11; four to a slot.  Same arithmetic and order as l1t_tile's epilogue.
+      f32x4 acc_prev[NT], acc_cur[NT];
+      float d_arg = 0.f, d_j = 0.f, d_r = 0.f, d_t = 0.f, d_de = 0.f;
+      f32x4 dw[2];          // (wx wx wy wy) of feature row r, ping-pong on r & 1
+      float db[2], dq[2];   // bias, quadrant offset + a quarter turn (derivative)
+      int pm_base = 0;      // base_p(mt - 1) + colP: first feature of the tile whose epilogue is in flight
+      auto dtable_load = [&](int r) __attribute__((always_inline)) {
+        const float* e = lds + L::FT + L::FTS * (pm_base + r);
+        dw[r & 1] = *reinterpret_cast<const f32x4*>(e);
+        db[r & 1] = e[4];
+        dq[r & 1] = e[8] + NFOPP_Q_UNIT;
+      };
+      auto epi_item = [&](int w) __attribute__((always_inline)) {
+        if (w >= 88) return;
+        const int e = w / 11, u = w % 11, r = e >> 1, tl = e & 1, b = r & 1;
+        if (u == 0) {
+          d_arg = fmaf(dw[b].z, uy[tl], db[b]);
+          if (tl == 0 && r + 1 < 4) dtable_load(r + 1);
+        }
+        if (u == 1) d_arg = fmaf(dw[b].x, ux[tl], d_arg);
+        if (u == 2) d_t = fmaf(d_arg, 0.159154943f, 12582912.0f);
+        if (u == 3) d_j = d_t - 12582912.0f;
+        if (u == 4) d_r = fmaf(d_j, -6.28318548202514648f, d_arg);
+        if (u == 5) d_r = fmaf(d_j, 1.74845553e-07f, d_r);
+        if (u == 6) d_t = fmaf(d_r, 0.159154943f, dq[b]);
+        if (u == 7) d_t = __builtin_amdgcn_sinf(d_t);
+        if (u == 8) d_de = acc_prev[tl][r] * d_t;
+        if (u == 9) gx[tl] = fmaf(d_de, dw[b].x, gx[tl]);
+        if (u == 10) gy[tl] = fmaf(d_de, dw[b].z, gy[tl]);
+      };
+      auto l1t_steps = [&](auto hook_c, int mt, f32x4 (&acc)[NT]) __attribute__((always_inline)) {
+        constexpr bool HOOK = decltype(hook_c)::value;
+        const int fbase = base_p(mt) + colP;
+        const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
+        const int lo_step = B::L1T + mt * B::HKB;
+        if (HOOK) { pm_base = base_p(mt - 1) + colP; dtable_load(0); }
+#pragma unroll
+        for (int kb = 0; kb < B::HKB; ++kb) {
+          const u32x4 al = q0t;
+          q0t = q1t;
+          q1t = lo_frag(lo_step + kb + 2);
+          fetcht(kb + 2 < B::HKB ? mt : mt + 1, (kb + 2) % B::HKB, wbt);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kb == TAIL_KB) {
+            const float wf = rebuild_weight(raw0t, al[0] & 0xffffu);
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma4(wf, tail_d[tl], acc[tl]);
+            pack_words(wat, ahnt, amnt);
+          } else {
+#define NFOPP_ACC(tl) acc[tl]
+#define NFOPP_L1T_WORK(q_)                                                                    \
+            if (HOOK) {                                                                        \
+              const int slot_ = kb * 8 + (q_) - ((q_) + 2) / 3;                                \
+              _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) epi_item(4 * slot_ + i_);      \
+            }
+            NFOPP_STEP_W(NFOPP_ACC, dh[kb < TAIL_KB ? kb : 0], dm[kb < TAIL_KB ? kb : 0], dl[kb < TAIL_KB ? kb : 0], aht, amt,
+                         al, kb + 1 < TAIL_KB, wat, ahnt, amnt, NFOPP_L1T_WORK)
+#undef NFOPP_L1T_WORK
+#undef NFOPP_ACC
+          }
+          aht = ahnt; amt = amnt; raw0t = wat[0];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wat[j] = wbt[j];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto epilogue = [&](auto ang_c, int mt, const f32x4 (&acc)[NT]) __attribute__((always_inline)) {   // as l1t_tile
+        constexpr bool ANG = decltype(ang_c)::value;
+        const int fbase = base_p(mt) + colP;
+        const float* fte = lds + L::FT + L::FTS * fbase;
+        const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
+        f32x2 gx2 = {gx[0], gx[NT - 1]}, gy2 = {gy[0], gy[NT - 1]}, gt2 = {gt[0], gt[NT - 1]};
+        f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};
+        if (ANG) isa4 = *reinterpret_cast<const f32x4*>(lds + L::ISA + fbase);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(fte + L::FTS * r + 4);
+          const f32x2 qh = *reinterpret_cast<const f32x2*>(fte + L::FTS * r + 8);
+          const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
+          const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
+          const f32x2 de = f32x2{acc[0][r], acc[NT - 1][r]} * cof;
+          gx2 = fma2(de, wx, gx2);
+          gy2 = fma2(de, wy, gy2);
+          if (ANG) gt2 = fma2(de, fr, gt2);
+        }
+        gx[0] = gx2.x; gx[NT - 1] = gx2.y; gy[0] = gy2.x; gy[NT - 1] = gy2.y; gt[0] = gt2.x; gt[NT - 1] = gt2.y;
+      };
+      // tiles 0 .. first_angle_kt-1 carry no angle features: their epilogues hide behind the next tile's steps
+      const int plain_tiles = first_angle_kt < NKT ? first_angle_kt : NKT - 1;   // epilogues that get a host tile
+      l1t_steps(std::false_type{}, 0, acc_prev);
 #pragma unroll 1
-    for (int mt = 0; mt < first_angle_kt; ++mt) l1t_tile(std::false_type{}, mt);
+      for (int mt = 1; mt <= plain_tiles; ++mt) {
+        l1t_steps(std::true_type{}, mt, acc_cur);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) acc_prev[tl] = acc_cur[tl];
+      }
+      // what is left: the epilogue of tile plain_tiles (angle tile or last tile) and the angle tiles behind it
+      if (plain_tiles >= first_angle_kt) epilogue(std::true_type{}, plain_tiles, acc_prev);
+      else epilogue(std::false_type{}, plain_tiles, acc_prev);
 #pragma unroll 1
-    for (int mt = first_angle_kt; mt < NKT; ++mt) l1t_tile(std::true_type{}, mt);
+      for (int mt = plain_tiles + 1; mt < NKT; ++mt) {
+        l1t_steps(std::false_type{}, mt, acc_cur);
+        epilogue(std::true_type{}, mt, acc_cur);
+      }
+    } else {
+#pragma unroll 1
+      for (int mt = 0; mt < first_angle_kt; ++mt) l1t_tile(std::false_type{}, mt);
+#pragma unroll 1
+      for (int mt = first_angle_kt; mt < NKT; ++mt) l1t_tile(std::true_type{}, mt);
+    }
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
       gx[tl] += __shfl_xor(gx[tl], 16); gx[tl] += __shfl_xor(gx[tl], 32);

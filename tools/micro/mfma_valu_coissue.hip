@@ -58,12 +58,49 @@ static void run(float* out, int threads) {
          best * 1e-3 * 2.4e9 / mfma_per_simd);
 }
 
+
+template <int NACC>
+__global__ __launch_bounds__(512) void k_chain(float* out, int iters, float seed) {
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
+  b[0] += threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m % NACC]) : "v"(a), "v"(b));
+  }
+  float s = seed;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NACC>
+static void run_chain(float* out, int threads) {
+  const int iters = 20000;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k_chain<NACC>, dim3(256), dim3(threads), 0, 0, out, iters, 1.0f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  printf("  %d independent accumulators per wave: %5.1f cycles per MFMA at 2.4 GHz\n", NACC,
+         best * 1e-3 * 2.4e9 / ((threads / 256.0) * iters * 8.0));
+}
+
 int main() {
   float* out;
   (void)hipMalloc(&out, 256 * 512 * 4);
   for (int threads : {256, 512}) {
     printf("%d waves per SIMD:\n", threads / 256);
     run<0>(out, threads); run<1>(out, threads); run<2>(out, threads); run<3>(out, threads);
+    printf("  dependent MFMA chains (no vector work):\n");
+    run_chain<1>(out, threads); run_chain<2>(out, threads); run_chain<4>(out, threads); run_chain<8>(out, threads);
     run<4>(out, threads); run<5>(out, threads);
     printf("  (6: 2 v_perm  7: s_waitcnt + 2 v_perm  8: v_and + v_sub  9: 1 v_pk_fma_f32  10: v_sin + v_fma)\n");
     run<6>(out, threads); run<7>(out, threads); run<8>(out, threads); run<9>(out, threads); run<10>(out, threads);
