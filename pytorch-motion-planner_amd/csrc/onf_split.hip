@@ -113,6 +113,19 @@ __device__ __forceinline__ void pack_words(const float w[8], u32x4& hi, u32x4& m
     }                                                                                                          \
   }
 
+// Development build (make EXTRA=-DNFOPP_PHASE_PROFILE): wave 0 of every workgroup accumulates clock ticks per phase of
+// the chunk loop; launch_split_t prints the shares every tenth launch of the <.., 2, 0> kernel.
+#ifdef NFOPP_PHASE_PROFILE
+#define NFOPP_TICK(SLOT)                                           \
+  {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();  \
+    phase_ticks[SLOT] += (float)(now_ - phase_t0);                 \
+    phase_t0 = now_;                                               \
+  }
+#else
+#define NFOPP_TICK(SLOT)
+#endif
+
 // ---- third-level blob: [gemm][step][lane] 16 bytes --------------------------------------------------------------
 template <int NKT>
 struct Blob {
@@ -216,6 +229,10 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane16, step * 1024, 0));
   };
 
+#ifdef NFOPP_PHASE_PROFILE
+  float phase_ticks[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned long long phase_t0 = __builtin_readcyclecounter();
+#endif
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // ---------------------------------------------------------------- sample / load the wave's points
     float ux[NT], uy[NT], th[NT];
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       th[tl] = ang;
     }
 
+    NFOPP_TICK(0)   // sampling
     // ---------------------------------------------------------------- L1: a1 = W1 in + b1, features just-in-time
     NFOPP_REDERIVE();
     f32x4 acc1[NT][HT];
@@ -486,6 +504,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       for (int kb = first_angle_kb; kb < B::NKB; ++kb) l1_block(std::true_type{}, kb);
     }
 
+    NFOPP_TICK(1)   // L1 (features + steps)
     // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
     NFOPP_REDERIVE();
     f32x4 acc2[NT][HT];
@@ -557,6 +576,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       }
     }
 
+    NFOPP_TICK(2)   // L2
     // ---------------------------------------------------------------- logit and dh2 = W3a * [a2 > 0]
     float logit[NT];
 #pragma unroll
@@ -589,6 +609,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
       continue;
     }
 
+    NFOPP_TICK(3)   // logit
     // ---------------------------------------------------------------- L2T: dh1 = (W2^T dh2) * [a1 > 0]
     NFOPP_REDERIVE();
     {
@@ -676,6 +697,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
             acc1[tl][mt][r] = ((mask1[tl] >> (4 * mt + r)) & 1u) ? accd[tl][mt][r] : 0.0f;  // dh1
     }
 
+    NFOPP_TICK(4)   // L2T
     // ---------------------------------------------------------------- L1T: din = W1^T dh1 + W3b, then the chain rule
     NFOPP_REDERIVE();
     float gx[NT], gy[NT], gt[NT];
@@ -899,6 +921,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
 #pragma unroll 1
       for (int mt = first_angle_kt; mt < NKT; ++mt) l1t_tile(std::true_type{}, mt);
     }
+    NFOPP_TICK(5)   // L1T (steps + epilogues)
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
       gx[tl] += __shfl_xor(gx[tl], 16); gx[tl] += __shfl_xor(gx[tl], 32);
@@ -909,7 +932,12 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
         *reinterpret_cast<f32x4*>(a.out4 + pidx[tl] * 4) = o;
       }
     }
+    NFOPP_TICK(6)   // output
   }
+#ifdef NFOPP_PHASE_PROFILE
+  if (MODE == 0 && a.ws_u && threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(a.ws_u + k, phase_ticks[k]);
+#endif
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -962,6 +990,28 @@ static int launch_split_t(const OnfKernelArgs& a, hipStream_t stream) {
   long long n_chunks = (a.n_points + CH - 1) / CH;
   long long grid = query_cus();
   if (grid > n_chunks) grid = n_chunks;
+#ifdef NFOPP_PHASE_PROFILE
+  if (MODE == 0 && NT == 2) {   // development only: synchronous, prints to stderr
+    static float* dbg = nullptr;
+    if (!dbg) NFOPP_HIP(hipMalloc(&dbg, 64));
+    NFOPP_HIP(hipMemsetAsync(dbg, 0, 64, stream));
+    OnfKernelArgs b = a;
+    b.ws_u = dbg;   // unused by this mode: carries the tick buffer
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), L::BYTES, stream, b, (const u32x4*)blob);
+    float h[8];
+    NFOPP_HIP(hipMemcpyAsync(h, dbg, 32, hipMemcpyDeviceToHost, stream));
+    NFOPP_HIP(hipStreamSynchronize(stream));
+    static int calls = 0;
+    if (++calls % 10 == 0) {
+      float tot = 0;
+      for (int k = 0; k < 7; ++k) tot += h[k];
+      const char* names[7] = {"sampling", "L1", "L2", "logit", "L2T", "L1T", "output"};
+      fprintf(stderr, "[phase profile] wave 0 of %lld workgroups, share of the chunk loop:\n", grid);
+      for (int k = 0; k < 7; ++k) fprintf(stderr, "   %-10s %5.1f %%\n", names[k], 100.0f * h[k] / tot);
+    }
+    return NFOPP_OK;
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), L::BYTES, stream, a, (const u32x4*)blob);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;
