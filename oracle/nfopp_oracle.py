@@ -5,8 +5,10 @@ planner step (MisterMap/pytorch-motion-planner, PyTorch-CPU + autograd).  It is 
 compared against; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.
 The product package (`pytorch-motion-planner_amd/nfopp`) never does.
 
-Pinned: every function below is checked in `tests/test_oracle_golden.py` against golden vectors produced by
-running the reference itself in the build container (`tests/golden/make_golden.py`, fixtures committed).
+Pinned: every function below is checked in `tests/test_oracle_golden.py` / `tests/test_path_tools_oracle.py` against
+golden vectors produced by running the reference itself in the build container (`tests/golden/make_golden.py`,
+fixtures committed); the device-RNG samplers restate the product's Philox stream and are checked in
+`tests/test_sampling_oracle.py`.
 
 Reference citations are `file:line` under the reference repo root; `nfop/` abbreviates
 `neural_field_optimal_planner/`.
