@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NFOPP_ABI_VERSION 3
+#define NFOPP_ABI_VERSION 4
 #define NFOPP_HIDDEN 100 /* width of both hidden layers, nfop/onf_model.py:18-23 */
 
 typedef enum nfopp_status {
@@ -93,11 +93,16 @@ int nfopp_onf_eval_logits(const nfopp_onf_config* cfg, const float* params_dev, 
  *                        (key = seed, counter = (global sample index, rng_offset)) and WRITTEN for the
  *                        update kernel;  traj_index_offset = global index of trajectory 0 (multi-GPU shards
  *                        draw the same numbers as a single-GPU run)
- *   out4_dev [B, N-1, 4] as nfopp_onf_eval_points */
+ *   out4_dev [B, N-1, 4] as nfopp_onf_eval_points
+ *   active_dev [B] uint8 or NULL (ABI 4): early stop, the reference's `break` (scripts/run_bench_mr.py:121-126).
+ *                        Trajectories with active == 0 are compacted OUT of the sample stream, so the kernel's
+ *                        work is proportional to the live ones; their t / out4 rows are left untouched and the
+ *                        rows of live trajectories are bit-identical to a launch without the mask.
+ *   live_ws_dev [B + 1] int32 workspace for the live list (required with active_dev, else may be NULL) */
 int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const float* params_dev, const float* traj_dev,
                               int64_t batch, int32_t n_waypoints, int32_t dim, float* t_dev, int32_t t_mode,
                               uint64_t seed, uint64_t rng_offset, int64_t traj_index_offset, float* out4_dev,
-                              void* stream);
+                              const uint8_t* active_dev, int32_t* live_ws_dev, void* stream);
 
 /* One `_optimize_trajectory` for every trajectory of the batch, given the ONF outputs at its samples:
  * loss terms + closed-form gradients (constrained:87-130, nerf:171-176), g <- H^-1 g (nerf:151), Adam
@@ -146,15 +151,16 @@ int nfopp_onf_train_grad_ex(const nfopp_onf_config* cfg, const float* params_dev
  * of nfop/collision_checker/collision_checker.py:12-19.
  *   circle:    any |pose.xy - obstacle| < radius                 nfop/collision_checker/circle_collision_checker.py:11-14
  *   rectangle: any obstacle inside box4 = (x0,x1,y0,y1) in the robot frame   .../rectangle_collision_checker.py:11-26
- *   grid:      uint8 occupancy image, cell = int((x - origin - cell/2)/cell); outside the image = collision
- *              (MapCollisionChecker, notebooks/onf_planner_image_map.ipynb cell 2) */
+ *   grid:      uint8 occupancy image, cell = int((x - origin - cell/2)/cell) in float64 like the reference's numpy
+ *              (geometry scalars are doubles since ABI 4); outside the image = collision
+ *              (MapCollisionChecker, notebooks/onf_planner_image_map.ipynb cell 2; labels pinned by tests/golden/g16) */
 int nfopp_check_collision_circle(const float* poses_dev, int64_t n, int32_t pose_dim, const float* obstacles_dev,
                                  int32_t n_obstacles, float radius, const float* bounds4, float* labels_dev,
                                  void* stream);
 int nfopp_check_collision_rectangle(const float* poses_dev, int64_t n, const float* obstacles_dev, int32_t n_obstacles,
                                     const float* box4, const float* bounds4, float* labels_dev, void* stream);
 int nfopp_check_collision_grid(const float* poses_dev, int64_t n, int32_t pose_dim, const uint8_t* grid_dev,
-                               int32_t rows, int32_t cols, float origin_x, float origin_y, float cell_size,
+                               int32_t rows, int32_t cols, double origin_x, double origin_y, double cell_size,
                                float* labels_dev, void* stream);
 
 /* Training-pose generation for every trajectory of a batch (nfop/nerf_opt_planner.py:101-120,135-141,

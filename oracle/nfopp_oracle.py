@@ -382,6 +382,64 @@ def optimize_trajectory(traj, start, goal, lam, cm, adam_m, adam_v, adam_step, t
     return new_traj, new_lam, new_cm, m, v, terms
 
 
+def _torch_row_sum(elems, zero):
+    """ATen `row_sum` (native/cpu/SumKernel.cpp): four interleaved accumulator chains over rows of 4 elements,
+    folded into the next cascade level every 16 rows (level_power = 4 for fewer than 2^21 elements)."""
+    size = len(elems)
+    rows = size // 4
+    acc = [[zero.copy() for _ in range(4)] for _ in range(4)]
+    i = 0
+    while i + 16 <= rows:
+        for _ in range(16):
+            for k in range(4):
+                acc[0][k] = (acc[0][k] + elems[i * 4 + k]).astype(F32)
+            i += 1
+        for j in range(1, 4):
+            for k in range(4):
+                acc[j][k] = (acc[j][k] + acc[j - 1][k]).astype(F32)
+                acc[j - 1][k] = zero.copy()
+            if i & (15 << (4 * j)):
+                break
+    while i < rows:
+        for k in range(4):
+            acc[0][k] = (acc[0][k] + elems[i * 4 + k]).astype(F32)
+        i += 1
+    for j in range(1, 4):
+        for k in range(4):
+            acc[0][k] = (acc[0][k] + acc[j][k]).astype(F32)
+    for r in range(rows * 4, size):
+        acc[0][0] = (acc[0][0] + elems[r]).astype(F32)
+    for k in range(1, 4):
+        acc[0][0] = (acc[0][0] + acc[0][k]).astype(F32)
+    return acc[0][0]
+
+
+def torch_sum_f32(a):
+    """`torch.sum` of a contiguous fp32 vector on CPU, bit for bit (ATen cascade sum with 8-float vectors -- the
+    SumKernel build that torch 2.10 dispatches to, also on AVX-512 hosts): lane columns summed by `_torch_row_sum`,
+    then the scalar tail, then the 8 lanes in order.  Checked against torch in tests/test_oracle_golden.py."""
+    a = np.asarray(a, F32)
+    n = len(a)
+    if n >= 8:
+        nv = n // 8
+        lanes = _torch_row_sum([a[i * 8:(i + 1) * 8] for i in range(nv)], np.zeros(8, F32))
+        fin = F32(0)
+        for k in range(nv * 8, n):
+            fin = F32(fin + a[k])
+        for k in range(8):
+            fin = F32(fin + lanes[k])
+        return fin
+    return F32(_torch_row_sum([np.asarray(x, F32) for x in a], np.asarray(0, F32)))
+
+
+def torch_norm2_f32(dx, dy):
+    """`torch.norm(dim=1)` of (dx, dy) rows on CPU: sqrt(fma(dy, dy, rn(dx*dx))) (NormTwoOps, contracted by gcc).
+    The fma is emulated in float64: the product and sum of fp32 values there round once more only in ties."""
+    dx, dy = np.asarray(dx, F32), np.asarray(dy, F32)
+    xx = (dx * dx).astype(F32).astype(np.float64)
+    return np.sqrt((xx + dy.astype(np.float64) * dy.astype(np.float64)).astype(F32)).astype(F32)
+
+
 def _searchsorted_left(cdf, u):
     return np.stack([np.searchsorted(cdf[b], u, side="left") for b in range(cdf.shape[0])])
 
@@ -391,10 +449,13 @@ def reparametrize(traj, start, goal, lam=None, cm=None):
     traj = np.asarray(traj, F32)
     B, N, D = traj.shape
     q = full_trajectory(traj, np.asarray(start, F32), np.asarray(goal, F32))
-    seg = q[:, 1:, :2] - q[:, :-1, :2]
-    dist = np.sqrt(np.sum(seg * seg, 2, dtype=F32)).astype(F32)
-    nd = (dist / dist.sum(1, dtype=F32)[:, None]).astype(F32)
-    cdf = np.concatenate([np.zeros((B, 1), F32), np.cumsum(nd, 1, dtype=F32)], 1)
+    seg = (q[:, 1:, :2] - q[:, :-1, :2]).astype(F32)
+    # the cdf feeds searchsorted (index work): torch-CPU roundings restated bit for bit -- torch.norm, torch.sum
+    # (cascade order) and torch.cumsum (float64 accumulator, every partial rounded to fp32)
+    dist = torch_norm2_f32(seg[..., 0], seg[..., 1])
+    total = np.asarray([torch_sum_f32(dist[b]) for b in range(B)], F32)
+    nd = (dist / total[:, None]).astype(F32)
+    cdf = np.concatenate([np.zeros((B, 1), F32), np.cumsum(nd.astype(np.float64), 1).astype(F32)], 1)
     u = linspace_f32(0, 1, N + 2)[1:-1]
     idx = _searchsorted_left(cdf, u)
     ia = np.where(idx > N + 1, N + 1, idx)
@@ -593,11 +654,13 @@ def resample_pool(cand, cand_age, logits, cap, seed, offset, traj_index_offset=0
 
 
 def grid_check(xy, grid, origin_x, origin_y, cell):
-    """MapCollisionChecker (notebooks/onf_planner_image_map.ipynb cell 2), fp32 arithmetic like the device kernel."""
-    xy = np.asarray(xy, F32)
+    """MapCollisionChecker (notebooks/onf_planner_image_map.ipynb cell 2): float64 index arithmetic on the poses
+    (numpy promotes them there), truncating int32 cast, outside [0, cols-1) x [0, rows-1) = collision.  Pinned by
+    tests/golden/g16_grid_checker.npz (labels of the notebook's own class)."""
+    xy = np.asarray(xy, np.float64)
     rows, cols = grid.shape
-    ix = ((xy[:, 0] - F32(origin_x) - F32(cell) / F32(2)) / F32(cell)).astype(np.int32)
-    iy = ((xy[:, 1] - F32(origin_y) - F32(cell) / F32(2)) / F32(cell)).astype(np.int32)
+    ix = ((xy[:, 0] - origin_x - cell / 2) / cell).astype(np.int32)
+    iy = ((xy[:, 1] - origin_y - cell / 2) / cell).astype(np.int32)
     inside = (ix >= 0) & (iy >= 0) & (iy < rows - 1) & (ix < cols - 1)
     out = np.ones(len(xy), bool)
     out[inside] = grid[iy[inside], ix[inside]] > 0

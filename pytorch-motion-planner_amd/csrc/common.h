@@ -26,6 +26,15 @@ int hip_fail(hipError_t e, const char* what);
     if (e__ != hipSuccess) return ::nfopp::hip_fail(e__, #call); \
   } while (0)
 
+// ---- per-device launch state (host) ------------------------------------------------------------------------------
+// One process may drive several GPUs: the dynamic-LDS attribute of a kernel and the CU count belong to the CURRENT
+// device's copy of the code object, so "already set" flags are kept per device (csrc/runtime.hip).
+constexpr int MAX_DEVICES = 64;
+int current_device();   // hipGetDevice, -1 on failure (error string set)
+// Raises the dynamic-LDS limit of `kernel` on the current device the first time it is launched there.
+// `flags` is the caller's static bool[MAX_DEVICES] for that kernel instantiation.
+int ensure_dynamic_lds(const void* kernel, size_t bytes, bool* flags);
+
 // ---- ONF parameter buffer geometry (state_dict order, include/nfopp_hip.h) --------------------------------------
 struct OnfGeom {
   int n_enc, n_sin, ang_dim, n_ang, fin, point_dim;

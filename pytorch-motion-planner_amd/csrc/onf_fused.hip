@@ -43,7 +43,8 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
   const float* W2 = lds + L::W2;
   constexpr int S1 = L::S1;
   constexpr int CH = WAVES * 16 * NT;
-  const long long n_chunks = (a.n_points + CH - 1) / CH;
+  const long long n_work = work_points(a);
+  const long long n_chunks = (n_work + CH - 1) / CH;
   const float b3 = a.params[geo.off_b3];
   constexpr int WIN = 16 * NKT;   // row length of the input-side factor matrices (TRAIN)
   constexpr int WH = 16 * HT;     // row length of the hidden-side factor matrices
@@ -55,46 +56,8 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
     long long pidx[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
-      long long p = chunk * CH + (wave * NT + tl) * 16 + i;
-      pidx[tl] = p;
-      if (p >= a.n_points) p = a.n_points - 1;
-      float x, y, ang = 0.f;
-      if (a.points) {
-        const float* q = a.points + p * geo.point_dim;
-        x = q[0]; y = q[1];
-        if (geo.point_dim == 3) ang = q[2];
-      } else {
-        const int nseg = a.n_way - 1;
-        long long b;
-        int j;
-        if (a.n_points < 0x7fffffffLL) {  // wave-uniform: 32-bit division for every realistic batch
-          const unsigned b32 = (unsigned)p / (unsigned)nseg;
-          b = b32;
-          j = (int)((unsigned)p - b32 * (unsigned)nseg);
-        } else {
-          b = p / nseg;
-          j = (int)(p - b * nseg);
-        }
-        float tt;
-        if (a.t_mode == 0) {
-          tt = a.t[p];
-        } else {
-          unsigned long long gp = (unsigned long long)((a.traj_index_offset + b) * nseg + j);
-          tt = philox_uniform(a.seed, gp, a.rng_offset);
-          if (g == 0 && pidx[tl] < a.n_points) a.t[p] = tt;
-        }
-        const float* qa = a.traj + (b * a.n_way + j) * a.dim;  // traj[:-1]
-        const float* qb = qa + a.dim;                           // traj[1:]
-        if (a.dim == 3) {
-          // constrained:79-81  p = traj[1:] + t * wrap-theta(traj[:-1] - traj[1:])
-          float dx = qa[0] - qb[0], dy = qa[1] - qb[1], dth = wrap_angle(qa[2] - qb[2]);
-          x = qb[0] + tt * dx; y = qb[1] + tt * dy; ang = qb[2] + tt * dth;
-        } else {
-          // nerf:117  p = traj[1:] * (1 - t) + traj[:-1] * t
-          float omt = 1.0f - tt;
-          x = qb[0] * omt + qa[0] * tt; y = qb[1] * omt + qa[1] * tt;
-        }
-      }
+      float x, y, ang;
+      pidx[tl] = load_point(a, n_work, chunk * CH + (wave * NT + tl) * 16 + i, g, x, y, ang);
       ux[tl] = (x - geo.mean) / geo.sigma;  // onf_model.py:38
       uy[tl] = (y - geo.mean) / geo.sigma;
       th[tl] = ang;
@@ -455,28 +418,25 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
-static int g_num_cus = 0;
+static int g_num_cus[MAX_DEVICES] = {};
 
 int query_cus() {
-  if (g_num_cus > 0) return g_num_cus;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  const int dev = current_device();
+  if (dev < 0) return 256;
+  if (g_num_cus[dev] > 0) return g_num_cus[dev];
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  return g_num_cus;
+  g_num_cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  return g_num_cus[dev];
 }
 
 template <int NKT, int NT, int MODE = 0>
 static int launch_t(const OnfKernelArgs& a, hipStream_t stream, int* grid_out = nullptr) {
   using L = Lds<NKT>;
-  static bool attr_set = false;
+  static bool attr_set[MAX_DEVICES] = {};
   auto kern = onf_fwd_bwd_kernel<NKT, NT, MODE>;
-  if (!attr_set) {
-    NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)L::BYTES));
-    attr_set = true;
-  }
+  const int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L::BYTES, attr_set);
+  if (rc_attr != NFOPP_OK) return rc_attr;
   constexpr int CH = WAVES * 16 * NT;
   long long n_chunks = (a.n_points + CH - 1) / CH;
   long long grid = query_cus();
@@ -537,6 +497,37 @@ int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* gri
 
 int onf_train_grid_upper_bound() { return query_cus(); }
 
+// ---- early stop: stable compaction of the live trajectory indices (one workgroup; B is a few thousand per GPU) ------
+// live[0] = count, live[1 + k] = index of the k-th trajectory with active[b] != 0, ascending.
+constexpr int CP_THREADS = 1024;
+__global__ __launch_bounds__(CP_THREADS) void compact_live_kernel(const unsigned char* active, long long batch, int* live) {
+  __shared__ int wave_sum[CP_THREADS / 64];
+  __shared__ int wave_off[CP_THREADS / 64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long per = (batch + CP_THREADS - 1) / CP_THREADS;
+  const long long lo = tid * per, hi = lo + per < batch ? lo + per : batch;
+  int mine = 0;
+  for (long long b = lo; b < hi; ++b) mine += active[b] != 0;
+  int scan = mine;   // inclusive scan over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(scan, o);
+    if (lane >= o) scan += up;
+  }
+  if (lane == 63) wave_sum[wave] = scan;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < CP_THREADS / 64; ++w) { wave_off[w] = run; run += wave_sum[w]; }
+    wave_off[CP_THREADS / 64] = run;
+    live[0] = run;
+  }
+  __syncthreads();
+  int pos = wave_off[wave] + scan - mine;
+  for (long long b = lo; b < hi; ++b)
+    if (active[b] != 0) live[1 + pos++] = (int)b;
+}
+
 }  // namespace nfopp
 
 using namespace nfopp;
@@ -570,7 +561,8 @@ extern "C" int nfopp_onf_eval_logits(const nfopp_onf_config* cfg, const float* p
 extern "C" int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const float* params_dev, const float* traj_dev,
                                          int64_t batch, int32_t n_waypoints, int32_t dim, float* t_dev,
                                          int32_t t_mode, uint64_t seed, uint64_t rng_offset,
-                                         int64_t traj_index_offset, float* out4_dev, void* stream) {
+                                         int64_t traj_index_offset, float* out4_dev, const uint8_t* active_dev,
+                                         int32_t* live_ws_dev, void* stream) {
   OnfKernelArgs a = {};
   NFOPP_REQUIRE(make_geom(cfg, &a.geom), "bad ONF configuration");
   NFOPP_REQUIRE(batch >= 0 && n_waypoints >= 2, "need batch >= 0 and at least 2 waypoints");
@@ -578,6 +570,15 @@ extern "C" int nfopp_traj_collision_eval(const nfopp_onf_config* cfg, const floa
   NFOPP_REQUIRE(dim == a.geom.point_dim, "trajectory dim %d does not match the ONF point dim %d", dim,
                 a.geom.point_dim);
   NFOPP_REQUIRE(t_mode == 0 || t_mode == 1, "t_mode must be 0 (read) or 1 (Philox)");
+  NFOPP_REQUIRE(batch <= 0x7fffffffLL, "batch too large for one launch");
+  NFOPP_REQUIRE(!active_dev || live_ws_dev, "an active mask needs the live-list workspace (batch + 1 int32)");
+  if (batch == 0) return NFOPP_OK;
+  if (active_dev) {
+    hipLaunchKernelGGL(compact_live_kernel, dim3(1), dim3(CP_THREADS), 0, (hipStream_t)stream, active_dev,
+                       (long long)batch, live_ws_dev);
+    NFOPP_HIP(hipGetLastError());
+    a.live = live_ws_dev;
+  }
   a.params = params_dev;
   a.traj = traj_dev;
   a.n_way = n_waypoints;

@@ -18,6 +18,9 @@ struct OnfKernelArgs {
   unsigned long long seed, rng_offset;
   long long traj_index_offset;
   long long n_points;
+  // early stop (trajectory mode): live[0] = number of live trajectories, live[1 + k] = index of the k-th one (ascending).
+  // The kernel then walks live[0] * (n_way - 1) samples; t / out4 rows keep their place (trajectory * (n_way-1) + j).
+  const int* live;
   float* out4;
   // training mode (TRAIN kernels only): labels, BCE normalisation, per-sample factor matrices for the weight-gradient
   // GEMMs (csrc/onf_wgrad.hip), per-wave loss partials

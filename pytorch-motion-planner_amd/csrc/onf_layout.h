@@ -136,4 +136,59 @@ __device__ __forceinline__ f32x2 features2(f32x2 wx, f32x2 wy, f32x2 b, f32x2 fr
   return sin_halfturns2(arg, DERIV ? qh + splat2(NFOPP_Q_UNIT) : qh);
 }
 
+// ---- the wave's points: explicit poses or collision samples of a trajectory batch --------------------------------
+// Number of samples this launch walks: all of them, or only those of the live trajectories (early stop).
+__device__ __forceinline__ long long work_points(const OnfKernelArgs& a) {
+  return a.live ? (long long)a.live[0] * (a.n_way - 1) : a.n_points;
+}
+
+// Pose of work item p (padding lanes past n_work repeat the last item).  Returns the row its outputs belong to --
+// a.n_points for a padding lane, so `row < a.n_points` is the store predicate.  Trajectory mode draws / reads the
+// interpolation parameter and forms the collision sample: constrained:78-81 (SE(2)) / nerf:113-117 (2-D).
+__device__ __forceinline__ long long load_point(const OnfKernelArgs& a, long long n_work, long long p, int g, float& x,
+                                                float& y, float& ang) {
+  const bool valid = p < n_work;
+  if (!valid) p = n_work - 1;
+  ang = 0.f;
+  if (a.points) {
+    const float* q = a.points + p * a.geom.point_dim;
+    x = q[0]; y = q[1];
+    if (a.geom.point_dim == 3) ang = q[2];
+    return valid ? p : a.n_points;
+  }
+  const int nseg = a.n_way - 1;
+  long long b;
+  int j;
+  if (a.n_points < 0x7fffffffLL) {  // wave-uniform: 32-bit division for every realistic batch
+    const unsigned b32 = (unsigned)p / (unsigned)nseg;
+    b = b32;
+    j = (int)((unsigned)p - b32 * (unsigned)nseg);
+  } else {
+    b = p / nseg;
+    j = (int)(p - b * nseg);
+  }
+  if (a.live) b = a.live[1 + b];
+  const long long row = b * nseg + j;
+  float tt;
+  if (a.t_mode == 0) {
+    tt = a.t[row];
+  } else {
+    unsigned long long gp = (unsigned long long)((a.traj_index_offset + b) * nseg + j);
+    tt = philox_uniform(a.seed, gp, a.rng_offset);
+    if (g == 0 && valid) a.t[row] = tt;
+  }
+  const float* qa = a.traj + (b * a.n_way + j) * a.dim;  // traj[:-1]
+  const float* qb = qa + a.dim;                           // traj[1:]
+  if (a.dim == 3) {
+    // constrained:79-81  p = traj[1:] + t * wrap-theta(traj[:-1] - traj[1:])
+    float dx = qa[0] - qb[0], dy = qa[1] - qb[1], dth = wrap_angle(qa[2] - qb[2]);
+    x = qb[0] + tt * dx; y = qb[1] + tt * dy; ang = qb[2] + tt * dth;
+  } else {
+    // nerf:117  p = traj[1:] * (1 - t) + traj[:-1] * t
+    float omt = 1.0f - tt;
+    x = qb[0] * omt + qa[0] * tt; y = qb[1] * omt + qa[1] * tt;
+  }
+  return valid ? row : a.n_points;
+}
+
 }  // namespace nfopp

@@ -23,6 +23,8 @@
 // k blocks pair the accumulator tiles (2kb, 2kb+1): element j of a lane's fragment is register j&3 of tile 2kb+(j>>2).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "onf_layout.h"
 
 namespace nfopp {
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
   const float* W2 = lds + L::W2;
   constexpr int S1 = L::S1;
   constexpr int CH = WAVES * 16 * NT;
-  const long long n_chunks = (a.n_points + CH - 1) / CH;
+  const long long n_work = work_points(a);
+  const long long n_chunks = (n_work + CH - 1) / CH;
   const float b3 = a.params[geo.off_b3];
   // third-level fragments through a buffer resource: address = base (4 scalar registers, built once) + 16 * lane (ONE
   // vector register for the whole kernel) + the step's byte offset (a scalar operand) -- no per-step 64-bit vector
@@ -239,44 +242,8 @@ __global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelAr
     long long pidx[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
-      long long p = chunk * CH + (wave * NT + tl) * 16 + i;
-      pidx[tl] = p;
-      if (p >= a.n_points) p = a.n_points - 1;
-      float x, y, ang = 0.f;
-      if (a.points) {
-        const float* q = a.points + p * geo.point_dim;
-        x = q[0]; y = q[1];
-        if (geo.point_dim == 3) ang = q[2];
-      } else {
-        const int nseg = a.n_way - 1;
-        long long b;
-        int j;
-        if (a.n_points < 0x7fffffffLL) {
-          const unsigned b32 = (unsigned)p / (unsigned)nseg;
-          b = b32;
-          j = (int)((unsigned)p - b32 * (unsigned)nseg);
-        } else {
-          b = p / nseg;
-          j = (int)(p - b * nseg);
-        }
-        float tt;
-        if (a.t_mode == 0) {
-          tt = a.t[p];
-        } else {
-          unsigned long long gp = (unsigned long long)((a.traj_index_offset + b) * nseg + j);
-          tt = philox_uniform(a.seed, gp, a.rng_offset);
-          if (g == 0 && pidx[tl] < a.n_points) a.t[p] = tt;
-        }
-        const float* qa = a.traj + (b * a.n_way + j) * a.dim;
-        const float* qb = qa + a.dim;
-        if (a.dim == 3) {
-          float dx = qa[0] - qb[0], dy = qa[1] - qb[1], dth = wrap_angle(qa[2] - qb[2]);
-          x = qb[0] + tt * dx; y = qb[1] + tt * dy; ang = qb[2] + tt * dth;
-        } else {
-          float omt = 1.0f - tt;
-          x = qb[0] * omt + qa[0] * tt; y = qb[1] * omt + qa[1] * tt;
-        }
-      }
+      float x, y, ang;
+      pidx[tl] = load_point(a, n_work, chunk * CH + (wave * NT + tl) * 16 + i, g, x, y, ang);
       ux[tl] = (x - geo.mean) / geo.sigma;
       uy[tl] = (y - geo.mean) / geo.sigma;
       th[tl] = ang;
@@ -951,21 +918,31 @@ bool onf_split_enabled() {
   return g_split_mode == 1;
 }
 
-constexpr int MAX_DEVICES = 16;
-static void* g_blob[MAX_DEVICES] = {};
-static size_t g_blob_bytes[MAX_DEVICES] = {};
+// Third-level blobs.  split_prep_kernel rewrites the blob in front of every launch ON THE LAUNCH STREAM, so launches of
+// one stream are ordered by the stream itself; two streams of one device (two planners with different fields) must not
+// share a blob, so blobs are keyed by (device, stream).  A handful of streams per device is the realistic case.
+constexpr int MAX_BLOBS = 16;
+struct BlobSlot { hipStream_t stream; void* ptr; size_t bytes; bool used; };
+static BlobSlot g_blobs[MAX_DEVICES][MAX_BLOBS] = {};
+static std::mutex g_blob_mutex;
 
-static int blob_for_device(size_t bytes, u32x4** out) {
-  int dev = 0;
-  NFOPP_HIP(hipGetDevice(&dev));
-  NFOPP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index %d out of range", dev);
-  if (g_blob_bytes[dev] < bytes) {
-    if (g_blob[dev]) NFOPP_HIP(hipFree(g_blob[dev]));
-    g_blob[dev] = nullptr; g_blob_bytes[dev] = 0;
-    NFOPP_HIP(hipMalloc(&g_blob[dev], bytes));
-    g_blob_bytes[dev] = bytes;
+static int blob_for_stream(size_t bytes, hipStream_t stream, u32x4** out) {
+  const int dev = current_device();
+  if (dev < 0) return NFOPP_ERR_HIP;
+  std::lock_guard<std::mutex> lock(g_blob_mutex);
+  BlobSlot* slot = nullptr;
+  for (int k = 0; k < MAX_BLOBS && !slot; ++k)
+    if (g_blobs[dev][k].used && g_blobs[dev][k].stream == stream) slot = &g_blobs[dev][k];
+  for (int k = 0; k < MAX_BLOBS && !slot; ++k)
+    if (!g_blobs[dev][k].used) { slot = &g_blobs[dev][k]; slot->used = true; slot->stream = stream; }
+  NFOPP_REQUIRE(slot, "more than %d streams launch the split-path ONF kernel on device %d", MAX_BLOBS, dev);
+  if (slot->bytes < bytes) {
+    if (slot->ptr) NFOPP_HIP(hipFree(slot->ptr));
+    slot->ptr = nullptr; slot->bytes = 0;
+    NFOPP_HIP(hipMalloc(&slot->ptr, bytes));
+    slot->bytes = bytes;
   }
-  *out = reinterpret_cast<u32x4*>(g_blob[dev]);
+  *out = reinterpret_cast<u32x4*>(slot->ptr);
   return NFOPP_OK;
 }
 
@@ -973,15 +950,12 @@ template <int NKT, int NT, int MODE>
 static int launch_split_t(const OnfKernelArgs& a, hipStream_t stream) {
   using L = Lds<NKT>;
   using B = Blob<NKT>;
-  static bool attr_set = false;
+  static bool attr_set[MAX_DEVICES] = {};
   auto kern = onf_split_kernel<NKT, NT, MODE>;
-  if (!attr_set) {
-    NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)L::BYTES));
-    attr_set = true;
-  }
+  int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L::BYTES, attr_set);
+  if (rc != NFOPP_OK) return rc;
   u32x4* blob = nullptr;
-  int rc = blob_for_device(B::BYTES, &blob);
+  rc = blob_for_stream(B::BYTES, stream, &blob);
   if (rc != NFOPP_OK) return rc;
   // third weight level in consumption order (the parameters may have changed since the last call: always rebuilt)
   hipLaunchKernelGGL(split_prep_kernel<NKT>, dim3(B::STEPS), dim3(64), 0, stream, a.geom, a.params, blob);

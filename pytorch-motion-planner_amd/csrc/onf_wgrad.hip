@@ -297,13 +297,10 @@ size_t wgrad_workspace_bytes(const OnfGeom& g, long long P) { return (size_t)car
 template <int NKT>
 static int launch_wgrad(const WgradArgs& a, int grid, hipStream_t st) {
   using W = WgLayout<NKT>;
-  static bool attr_set = false;
+  static bool attr_set[MAX_DEVICES] = {};
   auto kern = onf_wgrad_kernel<NKT>;
-  if (!attr_set) {
-    NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)W::LDS_BYTES));
-    attr_set = true;
-  }
+  const int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), W::LDS_BYTES, attr_set);
+  if (rc_attr != NFOPP_OK) return rc_attr;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG_THREADS), W::LDS_BYTES, st, a);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;

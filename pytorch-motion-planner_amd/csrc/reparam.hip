@@ -4,12 +4,56 @@
 // Replaces nfop/constrained_nerf_opt_planner.py:132-171 (SE(2): waypoints + both multiplier arrays) and
 // nfop/nerf_opt_planner.py:224-244 (2-D): xy segment lengths -> normalised cumulative distribution ->
 // searchsorted(left) of the uniform grid -> linear interpolation (theta along the wrapped difference).
-// The cumulative sum is accumulated sequentially in fp32 like torch.cumsum on CPU.
+//
+// searchsorted is INDEX work: the cdf must equal torch's bit for bit or a grid value that ties with a cdf entry lands
+// on the other side of a flat run.  So the three roundings that build the cdf are torch-CPU's (each checked against
+// torch in tests/test_oracle_golden.py::test_torch_reduction_orders and pinned by tests/golden/g4_reparam[clamp]):
+//   * torch.norm(dim=1) of an (dx, dy) row = sqrt(fma(dy, dy, rn(dx*dx)))   (NormTwoOps `acc + data*data`, contracted)
+//   * torch.sum of N+1 floats = ATen's cascade sum (SumKernel.cpp, the 8-float-vector build): 8 lane columns, four
+//     interleaved accumulator chains per lane folded every 16 rows, then the scalar tail, then the lanes in order
+//   * torch.cumsum accumulates in float64 (at::acc_type<float, false>) and rounds every partial sum to fp32
 #include "common.h"
 
 namespace nfopp {
 
 constexpr int RP_THREADS = 256;
+
+// ATen row_sum (native/cpu/SumKernel.cpp): element i = a[i * stride]; ilp_factor 4, cascade levels of 16 rows.
+// level_power = max(4, ceil_log2(size / 4) / 4) = 4 for every size below 2^21 elements (LDS bounds N far below that).
+__device__ __forceinline__ float torch_row_sum(const float* a, int stride, int size) {
+  float acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[j][k] = 0.f;
+  const int rows = size / 4;
+  int i = 0;
+  while (i + 16 <= rows) {
+    for (int j = 0; j < 16; ++j, ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[0][k] += a[(i * 4 + k) * stride];
+    }
+    bool more = true;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[j][k] += acc[j - 1][k]; acc[j - 1][k] = 0.f; }
+        if ((i & (15 << (4 * j))) != 0) more = false;
+      }
+    }
+  }
+  for (; i < rows; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[0][k] += a[(i * 4 + k) * stride];
+  }
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[0][k] += acc[j][k];
+  for (int r = rows * 4; r < size; ++r) acc[0][0] += a[r * stride];
+  return ((acc[0][0] + acc[0][1]) + acc[0][2]) + acc[0][3];
+}
 
 struct ReparamArgs {
   int n, dim;
@@ -33,7 +77,7 @@ __global__ __launch_bounds__(RP_THREADS) void reparam_kernel(const ReparamArgs a
   float* cmf = cdf + (N + 2);     // N+2   [0, cm, 0]
   float* lf = cmf + (N + 2);      // N+2   [l0, mid-averages, lN]
   float* li = lf + (N + 2);       // N     interpolated multipliers
-  float* red = li + N;            // RP_THREADS/64
+  float* red = li + N;            // 8 lane sums of the torch-order reduction
 
   float* traj = a.traj + b * N * D;
   for (int k = tid; k < N * D; k += RP_THREADS) Q[D + k] = traj[k];
@@ -51,26 +95,30 @@ __global__ __launch_bounds__(RP_THREADS) void reparam_kernel(const ReparamArgs a
   }
   __syncthreads();
 
-  // segment lengths (xy only, constrained:45-47) and their sum
-  float part = 0.f;
+  // segment lengths (xy only, constrained:45-47), torch.norm rounding
   for (int s = tid; s <= N; s += RP_THREADS) {
     const float dx = Q[(s + 1) * D] - Q[s * D], dy = Q[(s + 1) * D + 1] - Q[s * D + 1];
-    const float d = sqrtf(dx * dx + dy * dy);
-    cdf[s + 1] = d;
-    part += d;
+    cdf[s + 1] = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-  if ((tid & 63) == 0) red[tid >> 6] = part;
   __syncthreads();
-  float total = 0.f;
-  for (int w = 0; w < RP_THREADS / 64; ++w) total += red[w];
+  // torch.sum(distances): vectorized_inner_sum with 8-float vectors when there are at least 8 elements
+  const int n_el = N + 1, n_vec = n_el >= 8 ? n_el / 8 : 0;
+  if (tid < 8 && n_vec > 0) red[tid] = torch_row_sum(cdf + 1 + tid, 8, n_vec);
+  __syncthreads();
   if (tid == 0) {
-    float run = 0.f;
+    float total;
+    if (n_vec > 0) {
+      total = 0.f;
+      for (int k = n_vec * 8; k < n_el; ++k) total += cdf[1 + k];
+      for (int l = 0; l < 8; ++l) total += red[l];
+    } else {
+      total = torch_row_sum(cdf + 1, 1, n_el);   // scalar_inner_sum
+    }
+    double run = 0.0;   // torch.cumsum on CPU: float64 accumulator, every partial rounded to fp32
     cdf[0] = 0.f;
     for (int s = 1; s <= N + 1; ++s) {
-      run += cdf[s] / total;
-      cdf[s] = run;
+      run += (double)(cdf[s] / total);
+      cdf[s] = (float)run;
     }
   }
   __syncthreads();
@@ -122,7 +170,7 @@ extern "C" int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t d
   ReparamArgs a;
   a.n = n_waypoints; a.dim = dim; a.traj = traj_dev; a.start = start_dev; a.goal = goal_dev;
   a.lam = lam_dev; a.cm = cm_dev; a.u = u_dev; a.active = active_dev;
-  const size_t lds = (size_t)((n_waypoints + 2) * dim + 3 * (n_waypoints + 2) + n_waypoints + RP_THREADS / 64) * 4;
+  const size_t lds = (size_t)((n_waypoints + 2) * dim + 3 * (n_waypoints + 2) + n_waypoints + 8) * 4;
   NFOPP_REQUIRE(lds <= 160 * 1024, "trajectory too long for one workgroup's LDS (%zu bytes)", lds);
   auto kern = dim == 3 ? reparam_kernel<3> : reparam_kernel<2>;
   if (lds > 64 * 1024)

@@ -20,6 +20,24 @@ int hip_fail(hipError_t e, const char* what) {
   return e == hipErrorNoDevice ? NFOPP_ERR_NO_DEVICE : NFOPP_ERR_HIP;
 }
 
+int current_device() {
+  int dev = -1;
+  const hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { hip_fail(e, "hipGetDevice"); return -1; }
+  if (dev < 0 || dev >= MAX_DEVICES) { set_error("device index %d out of range", dev); return -1; }
+  return dev;
+}
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes, bool* flags) {
+  const int dev = current_device();
+  if (dev < 0) return NFOPP_ERR_HIP;
+  if (!flags[dev]) {
+    NFOPP_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    flags[dev] = true;
+  }
+  return NFOPP_OK;
+}
+
 // torch.optim.Adam single-tensor path on a flat buffer (ONF weights: nfop/nerf_opt_planner.py:90)
 __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, long long n, float beta2, float omb1,
                                  float omb2, float eps, float step_size, float bc2_sqrt) {

@@ -147,7 +147,7 @@ struct CheckArgs {
   const float* obstacles; int n_obstacles;
   float radius; float box[4];
   int has_bounds; float bounds[4];
-  const unsigned char* grid; int rows, cols; float origin_x, origin_y, cell;
+  const unsigned char* grid; int rows, cols; double origin_x, origin_y, cell;
   float* labels;
 };
 
@@ -191,13 +191,16 @@ __global__ __launch_bounds__(SM_THREADS) void check_points_kernel(const CheckArg
   if (valid) a.labels[p] = (hit || out_of_bounds(a, x, y)) ? 1.0f : 0.0f;
 }
 
-// occupancy grid (onf_planner_image_map.ipynb cell 2): cell = int((x - origin - cell/2) / cell) truncated toward zero;
-// outside [0, cols-1) x [0, rows-1) counts as collision
+// occupancy grid (onf_planner_image_map.ipynb cell 2): cell = int((x - origin - cell/2) / cell) truncated toward zero,
+// evaluated in float64 like the reference's numpy (poses are float64 there; geometry scalars are Python doubles), so the
+// labels of fp32 poses equal the reference's bit for bit (tests/golden/g16); outside [0, cols-1) x [0, rows-1) = collision
 __global__ __launch_bounds__(SM_THREADS) void check_grid_kernel(const CheckArgs a) {
   const long long p = blockIdx.x * (long long)SM_THREADS + threadIdx.x;
   if (p >= a.n) return;
-  const float x = a.poses[p * a.dim], y = a.poses[p * a.dim + 1];
-  const int ix = (int)((x - a.origin_x - a.cell / 2) / a.cell), iy = (int)((y - a.origin_y - a.cell / 2) / a.cell);
+  const double x = a.poses[p * a.dim], y = a.poses[p * a.dim + 1];
+  const double fx = (x - a.origin_x - a.cell / 2) / a.cell, fy = (y - a.origin_y - a.cell / 2) / a.cell;
+  // numpy's float64 -> int32 cast truncates toward zero; far-away poses (|f| >= 2^31) are outside either way
+  const int ix = fabs(fx) < 2.0e9 ? (int)fx : -1, iy = fabs(fy) < 2.0e9 ? (int)fy : -1;
   bool hit = true;
   if (ix >= 0 && iy >= 0 && iy < a.rows - 1 && ix < a.cols - 1) hit = a.grid[(long long)iy * a.cols + ix] > 0;
   a.labels[p] = hit ? 1.0f : 0.0f;
@@ -252,12 +255,12 @@ extern "C" int nfopp_check_collision_rectangle(const float* poses_dev, int64_t n
 }
 
 extern "C" int nfopp_check_collision_grid(const float* poses_dev, int64_t n, int32_t pose_dim, const uint8_t* grid_dev,
-                                          int32_t rows, int32_t cols, float origin_x, float origin_y, float cell_size,
+                                          int32_t rows, int32_t cols, double origin_x, double origin_y, double cell_size,
                                           float* labels_dev, void* stream) {
   CheckArgs a = {};
   int rc = fill_common(&a, poses_dev, n, pose_dim, nullptr, labels_dev);
   if (rc) return rc;
-  NFOPP_REQUIRE(grid_dev && rows > 1 && cols > 1 && cell_size > 0.f, "bad occupancy grid");
+  NFOPP_REQUIRE(grid_dev && rows > 1 && cols > 1 && cell_size > 0.0, "bad occupancy grid");
   a.grid = grid_dev; a.rows = rows; a.cols = cols; a.origin_x = origin_x; a.origin_y = origin_y; a.cell = cell_size;
   return launch_check(a, 2, (hipStream_t)stream);
 }

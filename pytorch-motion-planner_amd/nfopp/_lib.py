@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnfopp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_TERMS = 8
 TERM_NAMES = ("total", "distance", "softplus_sum", "lambda_dot_c", "c_squared", "boundary", "cm_tanh", "direction")
 
@@ -44,7 +44,7 @@ _SIGNATURES = {
     "nfopp_onf_eval_logits": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, ctypes.c_int64, _P, _P]),
     "nfopp_traj_collision_eval": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, _P, ctypes.c_int64, ctypes.c_int32,
                                                  ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
-                                                 ctypes.c_int64, _P, _P]),
+                                                 ctypes.c_int64, _P, _P, _P, _P]),
     "nfopp_traj_update": (ctypes.c_int, [ctypes.POINTER(TrajHyperC), ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int32, _P, _P, _P]),
@@ -69,7 +69,7 @@ _SIGNATURES = {
     "nfopp_check_collision_rectangle": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int32,
                                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _P, _P]),
     "nfopp_check_collision_grid": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
-                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P]),
+                                                  ctypes.c_double, ctypes.c_double, ctypes.c_double, _P, _P]),
     "nfopp_sample_candidates": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                ctypes.POINTER(ctypes.c_float), ctypes.c_uint64, ctypes.c_uint64,
@@ -115,12 +115,24 @@ def require_gpu():
         raise NfoppError("no HIP device visible: the NFOPP hot path runs on MI355X only (no CPU fallback)")
 
 
+def require_current_device(tensor_index, current_index):
+    """Every launch takes its stream, its CU count and its scratch blobs from the CURRENT device, so a buffer that
+    lives on another GPU would be handed to a kernel queued on the wrong card (a memory fault without peer access,
+    silent cross-device traffic with it).  One process per GPU is the design; a process that drives several GPUs
+    must make the buffer's device current (`torch.cuda.set_device` / `with torch.cuda.device(...)`) around the call."""
+    if tensor_index != current_index:
+        raise NfoppError("buffer lives on cuda:%d but the current device is cuda:%d: make the planner's device "
+                         "current (torch.cuda.set_device) before calling into the HIP library"
+                         % (tensor_index, current_index))
+
+
 def ptr(t, dtype=torch.float32):
-    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    """Device pointer of a contiguous CUDA(HIP) tensor on the current device, or NULL for None."""
     if t is None:
         return None
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise NfoppError("expected a contiguous %s HIP tensor, got %s" % (dtype, _describe(t)))
+    require_current_device(t.device.index, torch.cuda.current_device())
     return t.data_ptr() or None   # empty tensors have no storage: pass NULL (the C side accepts it for size 0)
 
 

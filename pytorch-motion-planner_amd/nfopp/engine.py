@@ -139,7 +139,10 @@ class TrajectoryEngine(object):
         self.hinv_band = torch.tensor(band, **f32)
         self.u = torch.linspace(0, 1, N + 2)[1:-1].contiguous().to(self.device)  # CPU linspace: reference rounding
         self.seed, self.rng_offset, self.traj_index_offset = int(seed), 0, int(traj_index_offset)
-        self.active = None   # optional uint8 [B] mask: 0 = retired trajectory (early stop), left untouched by update/reparam
+        # optional uint8 [B] mask: 0 = retired trajectory (early stop).  Retired trajectories are compacted out of the
+        # ONF kernel's sample stream and skipped by update / reparam: their state stays bit for bit as it was.
+        self.active = None
+        self._live = None    # int32 [B+1] live-list workspace of nfopp_traj_collision_eval
         self._check_traj()
 
     def _check_traj(self):
@@ -159,9 +162,14 @@ class TrajectoryEngine(object):
         else:
             mode = 1
         cfg = self.onf.config_c()
+        if self.active is not None and self._live is None:
+            self._live = torch.zeros(self.B + 1, dtype=torch.int32, device=self.device)
         _lib.check(lib.nfopp_traj_collision_eval(cfg, _lib.ptr(self.onf.flat_parameters), _lib.ptr(self.traj), self.B,
                                                  self.N, self.D, _lib.ptr(self.t), mode, self.seed, self.rng_offset,
-                                                 self.traj_index_offset, _lib.ptr(self.onf_out), _lib.stream_ptr()))
+                                                 self.traj_index_offset, _lib.ptr(self.onf_out),
+                                                 _lib.ptr(self.active, torch.uint8),
+                                                 _lib.ptr(self._live, torch.int32) if self.active is not None else None,
+                                                 _lib.stream_ptr()))
         if mode == 1:
             self.rng_offset += 1
 

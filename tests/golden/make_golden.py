@@ -11,7 +11,7 @@ Random draws are injected by re-seeding torch's CPU generator right before the r
 Outputs: small fp32 `.npz` fixtures next to this script.  Nothing from the reference's source text is
 written out -- only inputs and the numbers the reference computed from them.
 
-Usage:  MPLBACKEND=Agg python tests/golden/make_golden.py
+Usage:  MPLBACKEND=Agg python tests/golden/make_golden.py [generator ...]   (no names: all; see GENERATORS)
 """
 import os
 import sys
@@ -564,21 +564,230 @@ def g12_init_direction_and_postprocess():
     np.savez_compressed(os.path.join(HERE, "g12_init_dir_postprocess.npz"), **out)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# The settings the benchmark runs: scripts/run_bench_mr.py:19-63 hyper block on the random-disc map of bench.py
+BENCH_BOUNDS = (0.0, 100.0, 0.0, 100.0)
+
+
+def bench_discs():
+    """bench.py make_environment(): 300 discs r=1.5 on 100 m x 100 m."""
+    return np.random.default_rng(1234).uniform(5, 95, (300, 2)), 1.5
+
+
+def benchmr_params(n, init_iters, init_points):
+    """Parameter block of scripts/run_bench_mr.py:19-63 (values restated).  The A* seed is out of scope (bench-mr is
+    absent), so the stock TrajectoryInitializer is used; the field is pre-fitted by the reference's own
+    `_init_collision_model` (nerf_opt_planner.py:197-200) on uniform map samples."""
+    return AttributeDict(
+        device="cpu", trajectory_length=n,
+        trajectory_initializer=AttributeDict(name="TrajectoryInitializer", resolution=0.5,
+                                             init_angles_with_trajectory=False),
+        collision_model=AttributeDict(mean=0, sigma=10, use_cos=True, bias=True, use_normal_init=True,
+                                      angle_encoding=True, name="ONF"),
+        collision_optimizer=AttributeDict(lr=2e-2, betas=(0.9, 0.9)),
+        trajectory_optimizer=AttributeDict(lr=5e-2, betas=(0.9, 0.9)),
+        planner=AttributeDict(name="ConstrainedNERFOptPlanner", trajectory_random_offset=0.02, collision_weight=100,
+                              velocity_hessian_weight=0.5, random_field_points=10, init_collision_iteration=init_iters,
+                              constraint_deltas_weight=100, multipliers_lr=0.1, init_collision_points=init_points,
+                              reparametrize_trajectory_freq=10, optimize_collision_model_freq=1, angle_weight=5,
+                              angle_offset=0.3, boundary_weight=1, direction_delta_weight=100,
+                              collision_multipliers_lr=1e-3, collision_beta=10))
+
+
+def make_benchmr_planner(n, start, goal, init_iters=300, init_points=2000):
+    torch.random.manual_seed(100)
+    np.random.seed(400)
+    discs, radius = bench_discs()
+    cc = CircleDirectedCollisionChecker(radius, BENCH_BOUNDS)
+    cc.update_obstacle_points(discs)
+    planner = PlannerFactory.make_constrained_onf_planner(cc, benchmr_params(n, init_iters, init_points))
+    planner.init(np.asarray(start, F32), np.asarray(goal, F32), BENCH_BOUNDS)
+    torch.autograd.set_detect_anomaly(False)
+    return planner, cc
+
+
+def g13_benchmr(tag, n, warm, start, goal, rollout, init_points, learn_during_warm):
+    """G2/G3/G6 on the benchmarked settings: sigma=10 field AFTER fitting, w_col 100, beta 10, w_dir 100, aw 5,
+    lr 5e-2, random-disc map, N = 256 / 512.  The field is fitted by the reference's `_init_collision_model` (300
+    fits on `init_points` uniform map poses); then `warm` planner steps either with the field FROZEN (bench.py's
+    headline workload: pre-fitted frozen field) or with ONF learning on (the continuous-learning workload)."""
+    planner, cc = make_benchmr_planner(n, start, goal, init_points=init_points)
+    if not learn_during_warm:
+        freeze(planner)
+    for _ in range(warm):
+        if not learn_during_warm:
+            draw_t(n, 4100 + _)
+        planner.step()
+    freeze(planner)
+    discs, radius = bench_discs()
+    out = {"params": flat_params(planner._collision_model), "cfg": np.asarray([0, 10, 1, 1, 1], np.float64),
+           "vh_weight": np.asarray(0.5), "discs": discs, "radius": np.asarray(radius),
+           "fit_bce": np.asarray(field_bce(planner, cc))}
+    out.update(npz_hyper(hyper(planner)))
+    out.update({"s0_" + k: v for k, v in state(planner).items()})
+    out.update({"g2_" + k: v for k, v in terms_and_grads(planner, 5100).items()})
+    t = draw_t(n, 6100)
+    planner._optimize_trajectory()
+    out["g3_t"] = t.numpy()[:, 0].copy()
+    out.update({"g3_" + k: v for k, v in state(planner).items()})
+    ts, done = [], 0
+    for K in rollout:
+        while done < K:
+            t = draw_t(n, 7100 + done)
+            ts.append(t.numpy()[:, 0].copy())
+            planner.step()
+            done += 1
+        out.update({"g6_k%d_" % K + k: v for k, v in state(planner).items()})
+    out["g6_t"] = np.stack(ts).astype(F32)
+    np.savez_compressed(os.path.join(HERE, "traj_benchmr_%s.npz" % tag), **out)
+    return planner
+
+
+def field_bce(planner, cc):
+    """How well the fitted field separates the map: BCE on 4096 uniform poses (diagnostic stored with the fixture)."""
+    rng = np.random.default_rng(99)
+    x = np.concatenate([rng.uniform(0, 100, (4096, 2)), rng.uniform(0, 2 * np.pi, (4096, 1))], 1)
+    with torch.no_grad():
+        logit = planner._collision_model(torch.tensor(x.astype(F32)))
+        y = torch.tensor(cc.check_collision(Position2.from_vec(x)).astype(F32)[:, None])
+        return float(torch.nn.functional.binary_cross_entropy_with_logits(logit, y))
+
+
+def g14_benchmr_batch(base):
+    """Small batch on the benchmarked settings: B = 4 independent reference problems (N = 256) sharing the fitted
+    sigma=10 field of `base`, 12 frozen-field steps each with injected t (two reparametrisations)."""
+    sd = {k: v.clone() for k, v in base._collision_model.state_dict().items()}
+    starts = np.asarray([[8, 12, 0.3], [92, 9, 2.4], [50, 96, -1.6], [6, 55, 3.0]], F32)
+    goals = np.asarray([[90, 86, -2.5], [10, 90, 0.7], [47, 4, -1.5], [95, 48, -3.0]], F32)
+    K, n = 12, 256
+    out = {"params": flat_params(base._collision_model), "cfg": np.asarray([0, 10, 1, 1, 1], np.float64),
+           "starts": starts, "goals": goals}
+    trajs0, ts = [], []
+    snaps = {k: dict(traj=[], lam=[], cm=[]) for k in (1, 3, K)}   # early steps are gated tightly, the last loosely
+    for b in range(4):
+        p, _ = make_benchmr_planner(n, starts[b], goals[b], init_iters=0)
+        p._collision_model.load_state_dict(sd)
+        freeze(p)
+        if b == 0:
+            out.update(npz_hyper(hyper(p)))
+        trajs0.append(p._trajectory.detach().numpy().copy())
+        tb = []
+        for k in range(K):
+            t = draw_t(n, 9500 + 100 * b + k)
+            tb.append(t.numpy()[:, 0].copy())
+            p.step()
+            if k + 1 in snaps:
+                snaps[k + 1]["traj"].append(p._trajectory.detach().numpy().copy())
+                snaps[k + 1]["lam"].append(p._constraint_multipliers.detach().numpy().copy())
+                snaps[k + 1]["cm"].append(p._collision_multipliers.detach().numpy().copy())
+        ts.append(np.stack(tb))
+    out.update(traj0=np.stack(trajs0), t=np.stack(ts).astype(F32), steps=np.asarray(K), snapshots=np.asarray(sorted(snaps)))
+    for k, d in snaps.items():
+        out.update({"k%d_%s" % (k, name): np.stack(v) for name, v in d.items()})
+    np.savez_compressed(os.path.join(HERE, "g14_benchmr_batch.npz"), **out)
+
+
+def g15_full_steps_n256():
+    """BASELINE configs[1]: the drop-in `.step()` with ONF learning on, 1 trajectory x 256 waypoints, corridor
+    environment (scripts/benchmark.py configuration at N = 256, seeds torch 100 / numpy 400).  Field weights are
+    stored for the first and last step only (132 KB each)."""
+    planner, env = make_planner(256)
+    out = {"obstacles": env.obstacle_points.astype(np.float64), "bounds": np.asarray(env.bounds, np.float64),
+           "start": env.start_point, "goal": env.goal_point,
+           "params0": flat_params(planner._collision_model), "traj0": planner._trajectory.detach().numpy().copy()}
+    K = 6
+    for k in range(K):
+        planner.step()
+        out["k%d_traj" % k] = planner._trajectory.detach().numpy().copy()
+        out["k%d_checked" % k] = planner.checked_positions.as_vec().astype(np.float64)
+        out["k%d_truth" % k] = np.asarray(planner.truth_collision).astype(np.uint8)
+        if k in (0, K - 1):
+            out["k%d_params" % k] = flat_params(planner._collision_model)
+        out["k%d_lam" % k] = planner._constraint_multipliers.detach().numpy().copy()
+        out["k%d_cm" % k] = planner._collision_multipliers.detach().numpy().copy()
+    out["steps"] = np.asarray(K)
+    np.savez_compressed(os.path.join(HERE, "g15_full_steps_n256.npz"), **out)
+
+
+def corridor_grid(rows=100, cols=100, radius=3, seed=3, walkers=5, steps=150):
+    """Stand-in for bench-mr's corridor grid generator (absent): random-walk corridors of the given radius carved out
+    of a fully occupied 100 x 100 grid.  Our own generator -- the GRID is the committed fixture."""
+    rng = np.random.default_rng(seed)
+    grid = np.full((rows, cols), 255, np.uint8)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    for _ in range(walkers):
+        p = rng.uniform(10, 90, 2)
+        heading = rng.uniform(0, 2 * np.pi)
+        for _ in range(steps):
+            grid[(xx - p[0]) ** 2 + (yy - p[1]) ** 2 <= radius * radius] = 0
+            heading += rng.normal(0, 0.35)
+            p = p + 1.0 * np.asarray([np.cos(heading), np.sin(heading)])
+            if not (6 <= p[0] <= cols - 7 and 6 <= p[1] <= rows - 7):
+                heading += np.pi / 2 + rng.uniform(0, np.pi)
+                p = np.clip(p, [6, 6], [cols - 7, rows - 7])
+    return grid
+
+
+def g16_grid_checker():
+    """Occupancy-grid ground truth for BASELINE configs[3]: the committed 100 x 100 grid and the labels the
+    reference's own `MapCollisionChecker` (notebooks/onf_planner_image_map.ipynb, cell 2) gives for 6000 poses.
+    The cell's source is read from the reference at generation time and exec'd as is (it is numpy-only apart from
+    `draw_poly`, which needs cv2 and is never called); nothing of it is written out."""
+    import json
+    from dataclasses import dataclass
+    from neural_field_optimal_planner.collision_checker import CollisionChecker
+    with open(os.path.join(REF, "notebooks", "onf_planner_image_map.ipynb")) as f:
+        cell = "".join(json.load(f)["cells"][2]["source"])
+    ns = {"np": np, "dataclass": dataclass, "CollisionChecker": CollisionChecker}
+    exec(compile(cell, "onf_planner_image_map.ipynb#cell2", "exec"), ns)
+    grid = corridor_grid()
+    out = {"grid": grid}
+    rng = np.random.default_rng(16)
+    for tag, (ox, oy, cell_size) in {"unit": (0.0, 0.0, 1.0), "fine": (-20.0, -10.0, 0.4)}.items():
+        rows, cols = grid.shape
+        mi = ns["MapImage"](cols=cols, rows=rows, origin_x=ox, origin_y=oy, cell_size=cell_size,
+                            map_image=grid.astype(np.float64))
+        cc = ns["MapCollisionChecker"](mi, (ox, ox + cols * cell_size, oy, oy + rows * cell_size))
+        x = np.concatenate([rng.uniform(ox - 3 * cell_size, ox + (cols + 3) * cell_size, (3000, 1)),
+                            rng.uniform(oy - 3 * cell_size, oy + (rows + 3) * cell_size, (3000, 1)),
+                            rng.uniform(-np.pi, np.pi, (3000, 1))], 1)
+        # poses on and right next to cell edges (the truncating cast decides these) and around the outer rim
+        k = rng.integers(-1, cols + 1, (3000, 2)).astype(np.float64)
+        edge = np.stack([ox + (k[:, 0] + 0.5) * cell_size + rng.choice([-1e-3, 0, 1e-3], 3000) * cell_size,
+                         oy + (k[:, 1] + 0.5) * cell_size + rng.choice([-1e-3, 0, 1e-3], 3000) * cell_size,
+                         np.zeros(3000)], 1)
+        x = np.concatenate([x, edge]).astype(F32).astype(np.float64)   # exactly representable in fp32
+        out[tag + "_geom"] = np.asarray([ox, oy, cell_size])
+        out[tag + "_poses"] = x.astype(F32)
+        out[tag + "_truth"] = cc.check_collision(Position2.from_vec(x)).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "g16_grid_checker.npz"), **out)
+
+
+GENERATORS = {}
+
+
+def _register():
+    GENERATORS.update(
+        g1=g1_onf,
+        traj_n100_default=lambda: g2_g3_g6("n100_default", 100, 60),
+        traj_n100_hard=lambda: g2_g3_g6("n100_hard", 100, 60, start=[0.5, 0.5, 2.9], goal=[2.5, 1.5, -2.9],
+                                        rollout=(1, 10, 50),
+                                        over=dict(_collision_weight=3.0, _direction_delta_weight=7.0, _collision_beta=2.0),
+                                        push_out=True),
+        traj_n256_default=lambda: g2_g3_g6("n256_default", 256, 40, rollout=(1, 10)),
+        g4=g4_reparam, g5=g5_hinv, g7=g7_onf_train, g8=g8_batch, g9=g9_full_steps, g10=g10_planner2d,
+        g11=g11_init_and_checkers, g12=g12_init_direction_and_postprocess,
+        benchmr=lambda: g14_benchmr_batch(g13_benchmr("n256", 256, 60, [8, 12, 0.3], [90, 86, -2.5], (1, 10, 50), 4096, False)),
+        benchmr_n512=lambda: g13_benchmr("n512", 512, 40, [92, 9, 2.4], [10, 90, 0.7], (1, 10), 2000, True),
+        g15=g15_full_steps_n256, g16=g16_grid_checker)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    g1_onf()
-    g2_g3_g6("n100_default", 100, 60)
-    g2_g3_g6("n100_hard", 100, 60, start=[0.5, 0.5, 2.9], goal=[2.5, 1.5, -2.9], rollout=(1, 10, 50),
-             over=dict(_collision_weight=3.0, _direction_delta_weight=7.0, _collision_beta=2.0), push_out=True)
-    g2_g3_g6("n256_default", 256, 40, rollout=(1, 10))
-    g4_reparam()
-    g5_hinv()
-    g7_onf_train()
-    g8_batch()
-    g9_full_steps()
-    g10_planner2d()
-    g11_init_and_checkers()
-    g12_init_direction_and_postprocess()
+    _register()
+    # no arguments: every fixture; otherwise only the named generators (fixtures of earlier rounds stay untouched)
+    for name in (sys.argv[1:] or list(GENERATORS)):
+        GENERATORS[name]()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

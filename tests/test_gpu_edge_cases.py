@@ -109,8 +109,11 @@ def test_empty_batch_and_argument_errors():
     c = onf.config_c()
     x = torch.zeros(4, 3, device="cuda")
     assert lib.nfopp_traj_collision_eval(c, _lib.ptr(onf.flat_parameters), _lib.ptr(x), 1, 1, 3, _lib.ptr(x), 0, 0, 0, 0,
-                                         _lib.ptr(x), None) == -1                       # fewer than 2 waypoints
+                                         _lib.ptr(x), None, None, None) == -1           # fewer than 2 waypoints
     assert lib.nfopp_traj_collision_eval(c, _lib.ptr(onf.flat_parameters), _lib.ptr(x), 1, 4, 3, _lib.ptr(x), 7, 0, 0, 0,
-                                         _lib.ptr(x), None) == -1                       # bad t_mode
+                                         _lib.ptr(x), None, None, None) == -1           # bad t_mode
+    mask = torch.ones(1, dtype=torch.uint8, device="cuda")
+    assert lib.nfopp_traj_collision_eval(c, _lib.ptr(onf.flat_parameters), _lib.ptr(x), 1, 4, 3, _lib.ptr(x), 0, 0, 0, 0,
+                                         _lib.ptr(x), _lib.ptr(mask, torch.uint8), None, None) == -1   # mask without workspace
     with pytest.raises(nfopp.NfoppError):
         _lib.ptr(torch.zeros(3))                                                         # host tensor where a device one is due

@@ -23,14 +23,16 @@ F32 = np.float32
 @pytest.fixture
 def split_path():
     lib = _lib.load()
+    before = lib.nfopp_get_matrix_path()
     _lib.check(lib.nfopp_set_matrix_path(1))
     assert lib.nfopp_get_matrix_path() == 1
     yield lib
-    _lib.check(lib.nfopp_set_matrix_path(0))
+    _lib.check(lib.nfopp_set_matrix_path(before))   # the switch is process-wide: leave it as it was found
 
 
 def _eval(onf, x, path):
     lib = _lib.load()
+    before = lib.nfopp_get_matrix_path()
     _lib.check(lib.nfopp_set_matrix_path(path))
     try:
         out = onf.forward_with_grad(torch.tensor(np.ascontiguousarray(x, F32), device="cuda"))
@@ -38,7 +40,7 @@ def _eval(onf, x, path):
         torch.cuda.synchronize()
         return out.cpu().numpy(), logits.cpu().numpy().reshape(-1)
     finally:
-        _lib.check(lib.nfopp_set_matrix_path(0))
+        _lib.check(lib.nfopp_set_matrix_path(before))
 
 
 def _forward64(params, cfg, x):

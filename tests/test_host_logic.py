@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_header_symbol():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nfopp_abi_version() == 3
+    assert lib.nfopp_abi_version() == 4
     assert lib.nfopp_device_count() >= 0
 
 
@@ -56,6 +56,18 @@ def test_param_count_and_argument_errors_without_gpu():
     assert lib.nfopp_set_matrix_path(0) == 0 and lib.nfopp_get_matrix_path() == 0
     assert lib.nfopp_set_matrix_path(1) == 0 and lib.nfopp_get_matrix_path() == 1
     assert lib.nfopp_set_matrix_path(before) == 0
+    # ABI 4: an active mask needs its live-list workspace; the occupancy-grid geometry is float64
+    rc = lib.nfopp_check_collision_grid(None, 0, 2, None, 1, 1, 0.0, 0.0, 1.0, None, None)
+    assert rc == -1 and b"occupancy grid" in lib.nfopp_last_error()
+
+
+def test_device_guard_rejects_buffers_of_another_gpu():
+    """every launch uses the CURRENT device's stream / CU count / scratch, so `_lib.ptr` refuses a buffer that
+    lives on another card (the check itself is plain Python and needs no GPU)."""
+    _lib.require_current_device(0, 0)
+    _lib.require_current_device(3, 3)
+    with pytest.raises(nfopp.NfoppError, match="cuda:1 but the current device is cuda:0"):
+        _lib.require_current_device(1, 0)
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden, max_abs, max_rel
+from conftest import BENCHMR_FIXTURES, BENCHMR_ROLLOUT_TOL, check_batch_snapshot, load_golden, max_abs, max_rel
 from oracle import nfopp_oracle as orc
 
 F32 = np.float32
@@ -102,12 +102,27 @@ def test_g4_reparametrize(tag):
     z = load_golden("g4_reparam.npz")
     tr, lam, cm = orc.reparametrize(z[tag + "_in_traj"][None], z[tag + "_start"][None], z[tag + "_goal"][None],
                                     z[tag + "_in_lam"][None], z[tag + "_in_cm"][None])
-    # "wrap" has randomly tiny segments: tau = (u - cdf_b) / (cdf_a - cdf_b) amplifies the 1-ulp difference in
-    # the cdf normalisation (torch.sum vs numpy sum order) by 1/segment-length
-    tol = 5e-5 if tag == "wrap" else 5e-6
+    # the cdf is restated with torch's own roundings (norm / cascade sum / float64 cumsum), so searchsorted lands on
+    # the reference's indices in every case -- also on the 20 duplicated waypoints of "clamp", where the grid value
+    # ties with the cdf to 1 ulp -- and what is left is the rounding of the final lerps
+    tol = 2e-6
     assert max_abs(tr[0], z[tag + "_out_traj"]) < tol
     assert max_abs(lam[0], z[tag + "_out_lam"]) < tol
     assert max_abs(cm[0], z[tag + "_out_cm"]) < tol
+
+
+def test_torch_reduction_orders():
+    """The three torch-CPU roundings behind the reparametrisation cdf, against torch itself, bit for bit."""
+    import torch
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 140)) + [255, 256, 257, 258, 511, 513, 514, 1025, 2049, 4100]:
+        a = (rng.uniform(0, 1, n) ** 3).astype(F32)
+        assert float(torch.sum(torch.tensor(a))) == float(orc.torch_sum_f32(a)), n
+    d = rng.normal(0, 1, (50000, 2)).astype(F32)
+    assert np.array_equal(torch.norm(torch.tensor(d), dim=1).numpy(), orc.torch_norm2_f32(d[:, 0], d[:, 1]))
+    a = rng.uniform(0, 1, 513).astype(F32)
+    a /= a.sum()
+    assert np.array_equal(torch.cumsum(torch.tensor(a), 0).numpy(), np.cumsum(a.astype(np.float64)).astype(F32))
 
 
 def test_g5_inverse_hessian():
@@ -137,6 +152,80 @@ def test_g7_onf_training_step():
     assert max_abs(m, z["adam_m_after"]) < 1e-7
     assert max_abs(v, z["adam_v_after"]) < 1e-7
     assert max_abs(p, z["params_after"]) < 2e-6
+
+
+@pytest.mark.parametrize("name,ks", BENCHMR_FIXTURES)
+def test_benchmr_settings_terms_step_rollouts(name, ks):
+    """The settings bench.py runs (bench-mr hyper block, fitted sigma=10 field, 100 m disc map, N = 256 / 512): loss
+    terms + gradients, one optimiser step and frozen-field rollouts against the reference (G2/G3/G6 form)."""
+    z = load_golden(name)
+    cfg = orc.OnfConfig.from_vector(z["cfg"])
+    hp = orc.Hyper.from_npz(z)
+    assert (hp.collision_weight, hp.collision_beta, hp.direction_delta_weight, hp.angle_weight, hp.lr) == (100, 10, 100, 5, 5e-2)
+    n = z["s0_traj"].shape[0]
+    hinv = orc.calculate_inv_hessian(n, float(z["vh_weight"]))   # pinned by g5 (N = 256 and 512)
+    s = _state(z, "s0_")
+    t = z["g2_t"][None]
+    pts = orc.sample_collision_points(s["traj"], t)
+    assert max_abs(pts[0], z["g2_pos"]) < 1e-5                   # coordinates up to 100: 1 ulp = 7.6e-6
+    logit, dl = orc.onf_forward_grad(z["params"], cfg, pts[0])
+    assert scaled_err(logit, z["g2_logit"]) < 1e-5
+    terms = orc.trajectory_loss_terms(s["traj"], s["start"], s["goal"], s["lam"], s["cm"], t, logit[None], dl[None], hp)
+    for k in ("total", "l_dist", "l_col", "l_cm", "l_bnd"):
+        assert max_rel(terms[k][0], z["g2_" + k], 1e-4) < 2e-5, k
+    assert max_abs(terms["c"][0], z["g2_c"]) < 1e-6
+    assert max_abs(terms["d"][0], z["g2_d"]) < 1e-6
+    assert scaled_err(terms["g_traj"][0], z["g2_g_traj"]) < 2e-5
+    assert max_abs(terms["g_cm"][0], z["g2_g_cm"]) < 1e-5
+    if "n256" in name:   # the fixture exercises the linear softplus branch (beta * logit > 20) and the direction term
+        assert (10 * z["g2_logit"] > 20).sum() >= 1 and (z["g2_d"] > 0).sum() > 50
+    tr, lam, cm, m, v, _ = orc.optimize_trajectory(s["traj"], s["start"], s["goal"], s["lam"], s["cm"], s["adam_m"],
+                                                   s["adam_v"], s["adam_step"], z["g3_t"][None], z["params"], cfg, hp, hinv)
+    assert max_abs(tr[0], z["g3_traj"]) < 1e-5
+    assert max_abs(lam[0], z["g3_lam"]) < 1e-6
+    assert max_abs(cm[0], z["g3_cm"]) < 1e-6
+    assert scaled_err(m[0], z["g3_adam_m"]) < 1e-5
+    assert scaled_err(v[0], z["g3_adam_v"]) < 2e-5
+    s = _state(z, "g3_")
+    done = 0
+    for K in ks:
+        while done < K:
+            orc.planner_step(s, z["g6_t"][done][None], z["params"], cfg, hp, hinv)
+            done += 1
+        pre, tol = "g6_k%d_" % K, BENCHMR_ROLLOUT_TOL[K]
+        assert s["step_count"] == int(z[pre + "step_count"])
+        assert max_abs(s["traj"][0][:, :2], z[pre + "traj"][:, :2]) < tol["xy"], K
+        assert max_abs(s["traj"][0][:, 2], z[pre + "traj"][:, 2]) < tol["th"], K
+        assert max_abs(s["lam"][0], z[pre + "lam"]) < tol["lam"], K
+        assert max_abs(s["cm"][0], z[pre + "cm"]) < tol["cm"], K
+
+
+def test_benchmr_small_batch_equals_independent_runs():
+    """B = 4 reference problems on the benchmarked settings (N = 256, 12 steps from the straight-line start, two
+    reparametrisations), snapshots after steps 1 / 3 / 12 (gates: conftest.BENCHMR_BATCH_TOL)."""
+    z = load_golden("g14_benchmr_batch.npz")
+    cfg = orc.OnfConfig.from_vector(z["cfg"])
+    hp = orc.Hyper.from_npz(z)
+    B, N = z["traj0"].shape[:2]
+    hinv = orc.calculate_inv_hessian(N, 0.5)
+    s = dict(traj=z["traj0"].copy(), start=z["starts"], goal=z["goals"], lam=np.zeros((B, N + 1), F32),
+             cm=np.zeros((B, N), F32), adam_m=np.zeros((B, N, 3), F32), adam_v=np.zeros((B, N, 3), F32),
+             adam_step=0, step_count=1)
+    for k in range(int(z["steps"])):
+        orc.planner_step(s, z["t"][:, k], z["params"], cfg, hp, hinv)
+        if k + 1 in z["snapshots"]:
+            check_batch_snapshot(k + 1, s["traj"], s["lam"], s["cm"], z)
+
+
+def test_g16_grid_checker_labels():
+    """MapCollisionChecker labels made by the notebook's own class (cell 2 exec'd by make_golden.py g16)."""
+    z = load_golden("g16_grid_checker.npz")
+    assert z["grid"].shape == (100, 100) and 0.2 < (z["grid"] == 0).mean() < 0.5
+    for tag in ("unit", "fine"):
+        ox, oy, cell = (float(v) for v in z[tag + "_geom"])
+        got = orc.grid_check(z[tag + "_poses"][:, :2], z["grid"], ox, oy, cell)
+        assert np.array_equal(got.astype(np.uint8), z[tag + "_truth"])
+        assert 0.3 < z[tag + "_truth"].mean() < 0.9
 
 
 def test_g8_batch_equals_independent_runs():
