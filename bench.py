@@ -1,27 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native NFOPP inner loop.
 
-Metric (BASELINE.json): waypoint-evals/sec = trajectories x waypoints x planner steps / wall seconds.
-Workload at N GPUs (BASELINE configs[2] per GPU, i.e. configs[3] at 8 GPUs): 4096 trajectories x 256 waypoints per
-GPU, random-obstacle map (300 discs on 100 m x 100 m), SE(2) constrained planner with the bench-mr hyper-parameters
-(reference scripts/run_bench_mr.py:45-63), ONF F=220 pre-fitted on the map and then FROZEN.  One "step" is one
-planner `.step()` for every trajectory: fused collision sampling + ONF fwd/bwd (MFMA kernel), loss terms + H^-1 +
-Adam + multiplier ascent (stencil kernel), and the arc-length reparametrisation every 10th step.  Inputs are
-resident in HBM before the timed region; the per-step interpolation draws come from the in-kernel Philox stream.
+Metric (BASELINE.json): waypoint-evals/sec = trajectories x waypoints x planner steps / wall seconds, plus final-loss
+parity.  Workloads (per GPU; trajectories shard contiguously over ranks, weak scaling):
+
+  cfg3 (default, the configuration the metric is quoted on; = BASELINE configs[2], and configs[3]'s per-GPU share with
+        the disc map): 4096 trajectories x 256 waypoints, random-obstacle map (300 discs r = 1.5 on 100 m x 100 m), SE(2)
+        constrained planner with the bench-mr hyper-parameters (reference scripts/run_bench_mr.py:37-63), ONF F = 220
+        pre-fitted on the map and then FROZEN.
+  cfg4 (BASELINE configs[3] per GPU): the same on the committed 100 x 100 occupancy-grid map
+        (tests/golden/g16_grid_checker.npz; ground truth = DeviceGridChecker, pinned to the reference notebook's class).
+  cfg5 (BASELINE configs[4] per GPU): 4096 x 512, forward-only constraints, continuous ONF learning every step
+        (device sampling + checker + MFMA fit + one all-reduce of the ONF gradient buffer).
+
+One "step" is one planner `.step()` for every trajectory: fused collision sampling + ONF fwd/bwd (MFMA kernel), loss
+terms + H^-1 + Adam + multiplier ascent (stencil kernel), and the arc-length reparametrisation every 10th step.  Inputs
+are resident in HBM before the timed region; the interpolation draws come from the in-kernel Philox stream.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Trajectories shard contiguously across ranks (weak scaling, 4096 per GPU); the frozen-ONF step has no data-path
-collective.  Rank 0 prints ONE JSON line.  `roofline` = fused ONF kernel, algorithmic fp32 FLOPs (131 400 per
-collision sample) over its HIP-event duration vs the 157.3 TFLOP/s fp32 MFMA peak.  `cpu_baseline` =
-the oracle (oracle/nfopp_oracle.py, a numpy port with analytic gradients) timed on this host on a bounded sample.
+Rank 0 prints ONE JSON line.  Beside the contract's fields:
+  roofline      fused ONF kernel: algorithmic fp32 FLOPs (131 400 per collision sample) over its HIP-event
+                duration, against the pipe it runs on (see `roofline()`).
+  cpu_baseline  the STRONG CPU baseline (batched autograd-free torch restatement, all host cores) on a bounded sample;
+                `cpu_baseline_reference_faithful` = the eager-autograd single-trajectory restatement per core
+                (oracle/cpu_baselines.py, both validated against the reference's fixtures in tests/test_cpu_baselines.py;
+                timed in a child process that never touches the GPU).
+  parity        "final loss parity": (short) the first trajectories of THIS workload stepped by the GPU and by the numpy
+                oracle (pinned to the reference) on the identical Philox draw stream from the same initial state --
+                waypoint and per-term loss differences; (final) total loss and collision-free rate after all W + K
+                steps, GPU vs the CPU restatement on the same sample, and the GPU's collision-free rate over the batch.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -37,31 +54,71 @@ FLOP_PER_SAMPLE = 131400.0      # 65 700 FMA per collision sample (
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 SPLIT_PRODUCTS = 6              # bf16x3 split path: partial products issued per fp32 multiply (csrc/onf_split.hip)
-B_PER_GPU, N_WAYPOINTS = 4096, 256
+B_PER_GPU = 4096
 BOUNDS = (0.0, 100.0, 0.0, 100.0)
+SEED = 100
+HYPER = dict(collision_weight=100, angle_weight=5, constraint_deltas_weight=100, multipliers_lr=0.1,
+             collision_multipliers_lr=1e-3, boundary_weight=1, collision_beta=10, direction_delta_weight=100,
+             lr=5e-2, beta1=0.9, beta2=0.9, eps=1e-8)   # reference scripts/run_bench_mr.py:37-63
 
 
-def make_environment():
-    rng = np.random.default_rng(1234)
-    return rng.uniform(5, 95, (300, 2)), 1.5
+class DiscMap(object):
+    """300 discs r = 1.5 on 100 m x 100 m (bench-mr "random grid, obstacle ratio 0.03")."""
+    name = "random-obstacle map (300 discs r=1.5 on 100x100)"
+
+    def __init__(self):
+        self.discs, self.radius = np.random.default_rng(1234).uniform(5, 95, (300, 2)), 1.5
+
+    def in_collision(self, xy, margin=0.0):
+        d2 = ((xy[:, None, :] - self.discs[None]) ** 2).sum(-1)
+        out = (d2 < (self.radius + margin) ** 2).any(1)
+        return out | (xy[:, 0] < BOUNDS[0]) | (xy[:, 0] > BOUNDS[1]) | (xy[:, 1] < BOUNDS[2]) | (xy[:, 1] > BOUNDS[3])
+
+    def free_poses(self, rng, n):
+        out = np.zeros((0, 3))
+        while len(out) < n:
+            c = np.concatenate([rng.uniform(2, 98, (2 * n, 2)), rng.uniform(-np.pi, np.pi, (2 * n, 1))], 1)
+            out = np.concatenate([out, c[~self.in_collision(c[:, :2], 0.5)]])
+        return out[:n].astype(np.float32)
+
+    def device_checker(self, device):
+        return nfopp.DeviceCircleChecker(self.discs, self.radius, BOUNDS, device=device)
 
 
-def in_collision(xy, obstacles, radius):
-    d2 = ((xy[:, None, :] - obstacles[None]) ** 2).sum(-1)
-    out = (d2 < radius * radius).any(1)
-    out |= (xy[:, 0] < BOUNDS[0]) | (xy[:, 0] > BOUNDS[1]) | (xy[:, 1] < BOUNDS[2]) | (xy[:, 1] > BOUNDS[3])
-    return out
+class GridMap(object):
+    """The committed 100 x 100 occupancy grid (corridors of radius 3; bench-mr's own generator is absent)."""
+    name = "occupancy-grid map (100x100 cells of 1 m, random-walk corridors, tests/golden/g16_grid_checker.npz)"
+
+    def __init__(self):
+        self.grid = np.load(os.path.join(ROOT, "tests", "golden", "g16_grid_checker.npz"), allow_pickle=False)["grid"]
+
+    def in_collision(self, xy, margin=0.0):
+        # MapCollisionChecker arithmetic (notebooks/onf_planner_image_map.ipynb cell 2), origin (0, 0), cell 1 m
+        ix, iy = ((xy[:, 0] - 0.5) / 1.0).astype(np.int32), ((xy[:, 1] - 0.5) / 1.0).astype(np.int32)
+        ok = (ix >= 0) & (iy >= 0) & (iy < self.grid.shape[0] - 1) & (ix < self.grid.shape[1] - 1)
+        out = np.ones(len(xy), bool)
+        out[ok] = self.grid[iy[ok], ix[ok]] > 0
+        return out
+
+    def free_poses(self, rng, n):
+        # cells whose 3 x 3 neighbourhood is free, so that endpoints keep a clearance
+        g = self.grid == 0
+        core = g.copy()
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                core &= np.roll(np.roll(g, dy, 0), dx, 1)
+        core[[0, -1]] = False
+        core[:, [0, -1]] = False
+        cells = np.argwhere(core)
+        pick = cells[rng.integers(0, len(cells), n)]
+        xy = pick[:, ::-1] + 0.5 + rng.uniform(0.05, 0.95, (n, 2))
+        return np.concatenate([xy, rng.uniform(-np.pi, np.pi, (n, 1))], 1).astype(np.float32)
+
+    def device_checker(self, device):
+        return nfopp.DeviceGridChecker(self.grid, 0.0, 0.0, 1.0, device=device)
 
 
-def free_poses(rng, n, obstacles, radius):
-    out = np.zeros((0, 3))
-    while len(out) < n:
-        c = np.concatenate([rng.uniform(2, 98, (2 * n, 2)), rng.uniform(-np.pi, np.pi, (2 * n, 1))], 1)
-        out = np.concatenate([out, c[~in_collision(c[:, :2], obstacles, radius + 0.5)]])
-    return out[:n].astype(np.float32)
-
-
-def make_onf(device, obstacles, radius, fit_iters, fit_points):
+def make_onf(device, env, fit_iters, fit_points):
     """ONF of scripts/run_bench_mr.py:28-36 (sigma=10), fitted to the map with the HIP training kernel, then frozen."""
     torch.random.manual_seed(100)
     onf = nfopp.ONF(0, 10, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to(device)
@@ -69,63 +126,136 @@ def make_onf(device, obstacles, radius, fit_iters, fit_points):
     rng = np.random.default_rng(77)
     for _ in range(fit_iters):
         x = np.concatenate([rng.uniform(0, 100, (fit_points, 2)), rng.uniform(0, 2 * np.pi, (fit_points, 1))], 1)
-        y = in_collision(x[:, :2], obstacles, radius).astype(np.float32)
+        y = env.in_collision(x[:, :2]).astype(np.float32)
         fitter.step(torch.tensor(x.astype(np.float32), device=device), torch.tensor(y, device=device), global_count=fit_points)
     return onf, float(fitter.last_loss) if fit_iters else float("nan")
 
 
 def bench_hyper():
-    # reference scripts/run_bench_mr.py:37-63
-    return nfopp.TrajectoryHyper(collision_weight=100, angle_weight=5, constraint_deltas_weight=100, multipliers_lr=0.1,
-                                 collision_multipliers_lr=1e-3, boundary_weight=1, collision_beta=10,
-                                 direction_delta_weight=100, lr=5e-2, betas=(0.9, 0.9), eps=1e-8, bounds=BOUNDS)
+    h = dict(HYPER)
+    return nfopp.TrajectoryHyper(betas=(h.pop("beta1"), h.pop("beta2")), bounds=BOUNDS, **h)
 
 
-def cpu_baseline(onf_flat, starts, goals, sample_b, steps):
-    """Oracle (numpy port of the reference's algorithm) on the first `sample_b` trajectories of the workload."""
+# ---- CPU legs (the only places that touch oracle/) ----------------------------------------------------------------------
+def oracle_rollout(onf_flat, starts, goals, n, steps, index_offset=0):
+    """numpy oracle (pinned to the reference) on the DEVICE's draw stream: t[b, j] of step k = Philox(seed, counter =
+    global sample index (index_offset + b) * (N - 1) + j, k) -- csrc/onf_layout.h load_point.  Returns the final
+    state and the per-term loss sums of the first and the last step."""
     from oracle import nfopp_oracle as orc
-    try:
-        import threadpoolctl
-        threads = max([i["num_threads"] for i in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        threads = 1
     cfg = orc.OnfConfig(0, 10, True, True, True)
-    hp = orc.Hyper(100, 5, 100, 0.1, 1e-3, 1, 10, 100, 5e-2, 0.9, 0.9, 1e-8, BOUNDS)
-    n = N_WAYPOINTS
-    s = dict(traj=nfopp.straight_line_init(starts[:sample_b], goals[:sample_b], n), start=starts[:sample_b],
-             goal=goals[:sample_b], lam=np.zeros((sample_b, n + 1), np.float32), cm=np.zeros((sample_b, n), np.float32),
-             adam_m=np.zeros((sample_b, n, 3), np.float32), adam_v=np.zeros((sample_b, n, 3), np.float32),
-             adam_step=0, step_count=0)
+    hp = orc.Hyper(bounds=BOUNDS, **HYPER)
+    b = len(starts)
+    s = dict(traj=nfopp.straight_line_init(starts, goals, n), start=starts, goal=goals,
+             lam=np.zeros((b, n + 1), np.float32), cm=np.zeros((b, n), np.float32),
+             adam_m=np.zeros((b, n, 3), np.float32), adam_v=np.zeros((b, n, 3), np.float32), adam_step=0, step_count=0)
     hinv = orc.calculate_inv_hessian(n, 0.5)
-    rng = np.random.default_rng(5)
-    draw = lambda: rng.uniform(0, 1, (sample_b, n - 1)).astype(np.float32)  # noqa: E731
-    orc.planner_step(s, draw(), onf_flat, cfg, hp, hinv)  # warm-up
+    idx = (index_offset + np.arange(b)[:, None]) * (n - 1) + np.arange(n - 1)[None]
+    terms = []
     t0 = time.perf_counter()
+    for k in range(steps):
+        t = orc.philox_uniform(SEED, idx.reshape(-1), k).reshape(b, n - 1)
+        terms.append(orc.planner_step(s, t, onf_flat, cfg, hp, hinv))
+    return s, terms, time.perf_counter() - t0
+
+
+TERM_PAIRS = (("total", "total"), ("distance", "l_dist"), ("softplus_sum", "l_col"), ("lambda_dot_c", "l_lin"),
+              ("c_squared", "l_c2"), ("boundary", "l_bnd"), ("cm_tanh", "l_cm"), ("direction", "l_dir"))
+
+
+def short_parity(onf, starts, goals, n, sample, steps, device):
+    """GPU vs oracle from the same straight-line state on the same draws, `sample` trajectories, `steps` steps."""
+    gp = nfopp.BatchPlanner(onf, sample, n, bench_hyper(), velocity_hessian_weight=0.5, device=device, seed=SEED)
+    gp.init(starts[:sample], goals[:sample], BOUNDS)
+    gterms = []
     for _ in range(steps):
-        orc.planner_step(s, draw(), onf_flat, cfg, hp, hinv)
-    dt = time.perf_counter() - t0
-    return {"value": sample_b * n * steps / dt, "unit": "waypoint-evals/s", "cores": int(threads), "kind": "port",
-            "sample": "%d trajectories x %d waypoints x %d steps of the same workload (numpy oracle, %.1f s)"
-                      % (sample_b, n, steps, dt)}
+        gp.step(want_terms=True)
+        gterms.append(gp.engine.loss_terms())
+    got = gp.get_paths()[:, 1:-1]
+    s, oterms, cpu_s = oracle_rollout(onf.flat_parameters.cpu().numpy(), starts[:sample], goals[:sample], n, steps)
+    diff = np.abs(got.astype(np.float64) - s["traj"])
+    out = {"steps": steps, "trajectories": sample, "max_abs_traj": float(diff.max()),
+           "p99_abs_traj": float(np.percentile(diff, 99)), "median_abs_traj": float(np.median(diff)),
+           "oracle_seconds": cpu_s,
+           "note": "same initial state, same Philox t stream; straight-line starts make single entries ill-conditioned "
+                   "under Adam (the reference restarted 1 ulp away moves by 2 lr = 0.1 in such entries, tests/conftest.py)"}
+    for tag, k in (("first_step", 0), ("last_step", steps - 1)):
+        rel = {}
+        for ours, theirs in TERM_PAIRS:
+            a, b = float(np.sum(gterms[k][ours], dtype=np.float64)), float(np.sum(oterms[k][theirs], dtype=np.float64))
+            rel[ours] = abs(a - b) / max(abs(b), 1e-6)
+        out["loss_term_rel_diff_" + tag] = rel
+    return out
 
 
-def pmc_traffic(batch, n):
-    """HBM bytes per launch of the fused kernel from the committed PMC passes (profiles/r01_traffic.json, collected
-    with tools/gpu_pmc.sh on this workload); None when the workload differs or the file is absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            d = json.load(f)
-        return float(d["bytes_per_launch"]) if (batch, n) == (B_PER_GPU, N_WAYPOINTS) else None
-    except Exception:
-        return None
+def final_parity(planner, checker, onf, starts, goals, n, total_steps, sample):
+    """After all steps: mean total loss and collision-free rate, GPU (whole batch and the first `sample` rows) vs the CPU
+    restatement stepped the same number of times on the same draws (statistics, not waypoints: chaotic horizon)."""
+    from oracle import cpu_baselines as cb
+    eng = planner.engine
+    eng.collision_eval()
+    eng.update(True)                       # one more step, with the per-trajectory loss terms
+    torch.cuda.synchronize()
+    gpu_total = eng.loss_terms()["total"].astype(np.float64)
+    collides, _ = planner.evaluate(checker=checker, sub=4)
+    free = 1.0 - collides.cpu().numpy().astype(np.float64)
+    field = cb.Field(onf.flat_parameters.cpu().numpy(), 0, 10)
+    sc = cb.Scalars(bounds=BOUNDS, **HYPER)
+    cpu = cb.BatchedTorchPlanner(field, sc, nfopp.straight_line_init(starts[:sample], goals[:sample], n), starts[:sample],
+                                 goals[:sample])
+    from oracle import nfopp_oracle as orc
+    idx = (np.arange(sample)[:, None]) * (n - 1) + np.arange(n - 1)[None]
+    torch.set_num_threads(max(1, min(16, cb.usable_cores())))
+    for k in range(total_steps):
+        cpu.step(orc.philox_uniform(SEED, idx.reshape(-1), k).reshape(sample, n - 1))
+    cpu.optimize_trajectory(orc.philox_uniform(SEED, idx.reshape(-1), total_steps).reshape(sample, n - 1))
+    cpu_total = cpu.terms["total"].numpy().astype(np.float64)
+    dense, _ = orc.path_interpolate(cpu.traj.numpy(), starts[:sample], goals[:sample], 4)
+    cpu_lab = checker.labels(torch.tensor(dense.reshape(-1, 3), device=eng.device)).cpu().numpy().reshape(sample, -1)
+    gm, cm_ = float(gpu_total[:sample].mean()), float(cpu_total.mean())
+    return {"steps": total_steps + 1, "sample": sample,
+            "final_total_loss": {"gpu_batch_mean": float(gpu_total.mean()), "gpu_sample_mean": gm, "cpu_sample_mean": cm_,
+                                 "rel_diff": abs(gm - cm_) / max(abs(cm_), 1e-6)},
+            "collision_free_rate": {"gpu_batch": float(free.mean()), "gpu_sample": float(free[:sample].mean()),
+                                    "cpu_sample": float(1.0 - (cpu_lab != 0).any(1).mean())}}
 
 
-def roofline(matrix_path, achieved, k1_ms, samples, traffic):
+def cpu_baselines(onf_flat, starts, goals, n, sample_b, seconds):
+    """oracle/cpu_baselines.py in a child process (fresh interpreter, no GPU): strong batched torch-CPU baseline and the
+    reference-faithful eager baseline, on a bounded sample of this workload."""
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "in.npz")
+        kw = {"sc_" + k: np.asarray(v, np.float64) for k, v in dict(HYPER, bounds=BOUNDS).items()}
+        np.savez(path, onf_flat=onf_flat, onf_cfg=np.asarray([0, 10, 1, 1, 1], np.float64), n_waypoints=n,
+                 starts=starts[:sample_b], goals=goals[:sample_b], **kw)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baselines.py"), "--input", path,
+                              "--seconds-batched", str(seconds), "--seconds-eager", str(0.6 * seconds), "--procs", "1"],
+                             capture_output=True, text=True, env=env, timeout=600)
+    if res.returncode != 0:
+        raise RuntimeError("cpu_baselines.py failed:\n" + res.stderr[-2000:])
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+def pmc_traffic(workload, batch, n):
+    """HBM bytes per launch of the fused kernel from the newest committed PMC passes (profiles/r*_traffic.json, collected
+    with tools/gpu_pmc_split.sh on the cfg3 workload in separate --pmc passes); None for other workloads."""
+    if (workload, batch, n) != ("cfg3", B_PER_GPU, 256):
+        return None, None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)["bytes_per_launch"]), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def roofline(matrix_path, achieved, k1_ms, samples, traffic, traffic_source):
     """`achieved` is ALGORITHMIC fp32 FLOP/s of the fused ONF kernel in both cases.  fp32 path: against the fp32 MFMA
     peak.  Split path: the kernel runs on the bf16 matrix pipe and issues 6 bf16 partial products per fp32 multiply,
     so the peak that bounds it is the dense bf16 peak / 6 (fp32-equivalent); the fp32-MFMA ratio is given beside it."""
-    out = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": traffic, "kernel_ms": k1_ms,
-           "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE}
+    out = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_source,
+           "kernel_ms": k1_ms, "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE}
     if matrix_path == "split":
         peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
         out.update({"peak": peak, "frac": achieved / peak, "kernel": "onf_split_kernel<14,2,0>",
@@ -145,20 +275,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU)
     ap.add_argument("--fit-iters", type=int, default=300)
-    ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-steps", type=int, default=10)
-    ap.add_argument("--workload", choices=("cfg3", "cfg5"), default="cfg3",
-                    help="cfg3 (default, the headline): 4096x256 frozen field.  cfg5: 4096x512 per GPU with continuous "
-                         "ONF learning every step (device sampling + checker + MFMA fit + gradient all-reduce)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the CPU-baseline sample (0 = skip the CPU legs)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of each CPU baseline")
+    ap.add_argument("--parity-steps", type=int, default=10)
+    ap.add_argument("--workload", choices=("cfg3", "cfg4", "cfg5"), default="cfg3")
     ap.add_argument("--spin-up", type=int, default=300, help="throw-away steps during setup (clock ramp), state reset after")
-    ap.add_argument("--matrix-path", choices=("split", "fp32"), default="split",
-                    help="fused ONF kernel: bf16x3 split-precision MFMA (default, fp32-faithful) or fp32 MFMA")
+    ap.add_argument("--matrix-path", choices=("split", "fp32"), default=None,
+                    help="fused ONF kernel: bf16x3 split-precision MFMA (library default, fp32-faithful) or fp32 MFMA; "
+                         "not given = leave the library's choice (NFOPP_MATRIX_PATH) alone")
     args = ap.parse_args()
     from nfopp import _lib
-    _lib.check(_lib.load().nfopp_set_matrix_path(1 if args.matrix_path == "split" else 0))
-    global N_WAYPOINTS
-    if args.workload == "cfg5":
-        N_WAYPOINTS = 512
+    lib = _lib.load()
+    if args.matrix_path is not None:
+        _lib.check(lib.nfopp_set_matrix_path(1 if args.matrix_path == "split" else 0))
+    matrix_path = "split" if lib.nfopp_get_matrix_path() == 1 else "fp32"
+    N = 512 if args.workload == "cfg5" else 256
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,23 +309,23 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
 
-    B, N = args.batch_per_gpu, N_WAYPOINTS
-    obstacles, radius = make_environment()
-    onf, fit_loss = make_onf(device, obstacles, radius, args.fit_iters, 4096)
+    B = args.batch_per_gpu
+    env = GridMap() if args.workload == "cfg4" else DiscMap()
+    onf, fit_loss = make_onf(device, env, args.fit_iters, 4096)
     rng = np.random.default_rng(4321)
-    starts = free_poses(rng, world * B, obstacles, radius)
-    goals = free_poses(rng, world * B, obstacles, radius)
+    starts = env.free_poses(rng, world * B)
+    goals = env.free_poses(rng, world * B)
     lo, hi = nfopp.shard_range(world * B, rank, world)
-    checker = None
-    if args.workload == "cfg5":   # continuous learning: ground truth on the device, forward-only constraints on
-        checker = nfopp.DeviceCircleChecker(obstacles, radius, BOUNDS, device=device)
-    planner = nfopp.BatchPlanner(onf, hi - lo, N, bench_hyper(), velocity_hessian_weight=0.5, device=device, seed=100,
-                                 traj_index_offset=lo, checker=checker, fit_lr=2e-2, angle_offset=0.3)
+    truth = env.device_checker(device)
+    learn = args.workload == "cfg5"   # continuous learning: ground truth on the device, forward-only constraints on
+    planner = nfopp.BatchPlanner(onf, hi - lo, N, bench_hyper(), velocity_hessian_weight=0.5, device=device, seed=SEED,
+                                 traj_index_offset=lo, checker=truth if learn else None, fit_lr=2e-2, angle_offset=0.3,
+                                 global_batch=world * B)
     planner.init(starts[lo:hi], goals[lo:hi], BOUNDS)
     eng = planner.engine
 
     def one_step(ev=None):
-        if checker is not None and planner.step_count % planner.fit_freq == 0:
+        if learn and planner.step_count % planner.fit_freq == 0:
             planner.fit_field()
         if ev is not None:
             ev[0].record()
@@ -207,12 +338,14 @@ def main():
         planner.step_count += 1
 
     # setup, not measurement: a fresh box starts at idle clocks and the first process pays one-off costs (code-object
-    # load, DVFS ramp).  Spin the device up on throw-away steps, then restore the initial planner state.
+    # load, DVFS ramp).  Spin the device up on throw-away steps, then restore the initial planner state (and the draw
+    # stream: step k of the run uses Philox word k, which is what the CPU parity legs replay).
     for _ in range(args.spin_up):
         one_step()
     torch.cuda.synchronize()
     if args.spin_up:
         planner.init(starts[lo:hi], goals[lo:hi], BOUNDS)
+        eng.rng_offset = 0
     for _ in range(args.warmup):
         one_step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -239,26 +372,35 @@ def main():
         achieved = samples * FLOP_PER_SAMPLE / (k1_ms * 1e-3) / 1e12
         paths = planner.get_paths()
         finite = bool(np.isfinite(paths).all())
+        if learn:
+            workload = ("BASELINE configs[4] per GPU: %d trajectories x %d waypoints, forward-only constraints, continuous ONF "
+                        "learning every step on %d device-sampled poses per GPU, gradient all-reduce over ranks (last fit "
+                        "loss %.3f)" % (B, N, planner.sampler.B * planner.sampler.S, float(planner.fitter.last_loss)))
+        else:
+            workload = ("BASELINE configs[%d] per GPU: %d trajectories x %d waypoints, %s, SE(2) constrained planner, frozen "
+                        "pre-fitted ONF (F=220, fit loss %.3f)" % (3 if args.workload == "cfg4" else 2, B, N, env.name, fit_loss))
+        traffic, traffic_source = pmc_traffic(args.workload, B, N)
         out = {
             "metric": "waypoint-evals/sec", "value": world * B * N * args.steps / elapsed, "unit": "waypoint-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[2] per GPU: %d trajectories x %d waypoints, random-obstacle map "
-                                    "(300 discs r=1.5 on 100x100), SE(2) constrained planner, frozen pre-fitted ONF "
-                                    "(F=220, fit loss %.3f)" % (B, N, fit_loss)) if checker is None else
-                                   ("BASELINE configs[4] per GPU: %d trajectories x %d waypoints, forward-only constraints, "
-                                    "continuous ONF learning every step on %d device-sampled poses per GPU, gradient "
-                                    "all-reduce over ranks (last fit loss %.3f)"
-                                    % (B, N, planner.sampler.B * planner.sampler.S, float(planner.fitter.last_loss))),
-                       "trajectories_per_gpu": B, "waypoints": N, "global_batch": world * B,
-                       "parallelism": "trajectory shards, no data-path collective" if checker is None else "trajectory shards + one all-reduce of the 33163-float ONF gradient buffer per step", "paths_finite": finite, "matrix_path": args.matrix_path,
-                       "planner_steps_per_s": args.steps / elapsed},
-            "roofline": roofline(args.matrix_path, achieved, k1_ms, samples,
-                                 pmc_traffic(B, N) if checker is None else None),
+            "config": {"workload": workload, "trajectories_per_gpu": B, "waypoints": N, "global_batch": world * B,
+                       "parallelism": "trajectory shards + one all-reduce of the 33163-float ONF gradient buffer per step"
+                       if learn else "trajectory shards, no data-path collective",
+                       "paths_finite": finite, "matrix_path": matrix_path, "planner_steps_per_s": args.steps / elapsed},
+            "roofline": roofline(matrix_path, achieved, k1_ms, samples, traffic, traffic_source),
         }
         if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(onf.flat_parameters.cpu().numpy(), starts, goals,
-                                               min(args.cpu_sample, world * B), args.cpu_steps)
+            sample = min(args.cpu_sample, hi - lo)
+            flat = onf.flat_parameters.cpu().numpy()
+            cpu = cpu_baselines(flat, starts, goals, N, sample, args.cpu_seconds)
+            out["cpu_baseline"] = cpu["strong"]
+            out["cpu_baseline_reference_faithful"] = cpu["reference_faithful"]
+            out["cpu_host"] = {"visible_cores": cpu["host_cores"], "usable_cores": cpu["usable_cores"], "model": cpu["cpu_model"]}
+            if not learn:   # frozen field: the CPU legs can replay the run exactly
+                out["parity"] = {"short": short_parity(onf, starts, goals, N, sample, args.parity_steps, device),
+                                 "final": final_parity(planner, truth, onf, starts, goals, N, args.warmup + args.steps,
+                                                       min(32, sample))}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -90,6 +90,9 @@ class OnfFitter(object):
         return self.distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
 
     def global_count(self, local_count):
+        """Sample count over all ranks when the caller cannot state it: ONE extra all-reduce and a host sync.  The
+        hot loop never takes this path -- `BatchPlanner` passes the count it knows statically (global batch x poses per
+        trajectory); it exists for ragged, caller-managed sample sets."""
         if not self._in_group():
             return int(local_count)
         gloo = torch.distributed.get_backend(self.group) == "gloo"
@@ -97,8 +100,13 @@ class OnfFitter(object):
         torch.distributed.all_reduce(c, group=self.group)
         return int(c.item())
 
+    def world_size(self):
+        return torch.distributed.get_world_size(self.group) if self._in_group() else 1
+
     def step(self, samples, labels, global_count=None, adam_fn=None):
-        """samples [P_local, point_dim], labels [P_local] on this rank's device.  Returns the global mean loss tensor."""
+        """samples [P_local, point_dim], labels [P_local] on this rank's device.  `global_count` = number of samples
+        over ALL ranks (the BCE mean's denominator); pass it whenever it is known without communication.  Returns
+        the global mean loss (a device scalar; no host sync)."""
         p = samples.shape[0]
         total = self.global_count(p) if global_count is None else int(global_count)
         self._grad_fn(samples, labels, 1.0 / total)
@@ -127,8 +135,10 @@ class BatchPlanner(object):
                  device="cuda", seed=0, traj_index_offset=0, checker=None, fit_lr=2e-2, fit_betas=(0.9, 0.9),
                  optimize_collision_model_freq=1, trajectory_random_offset=0.02, course_random_offset=1.5,
                  angle_offset=0.0, random_field_points=10, collision_point_count=100, group=None,
-                 init_angles_with_trajectory=False):
+                 init_angles_with_trajectory=False, global_batch=None):
         self.init_angles_with_trajectory = bool(init_angles_with_trajectory)
+        # trajectories over ALL ranks (continuous learning: denominator of the BCE mean); default = equal shards
+        self.global_batch = None if global_batch is None else int(global_batch)
         self.engine = TrajectoryEngine(onf, batch, n_waypoints, onf.point_dim, hyper, velocity_hessian_weight, device,
                                        seed=seed, traj_index_offset=traj_index_offset)
         self.onf = onf
@@ -172,7 +182,9 @@ class BatchPlanner(object):
         samples = self.sampler.draw(self._prev, eng.hyper.bounds)
         self._prev.copy_(eng.traj)
         labels = self.checker.labels(samples, out=self.sampler.labels)
-        return self.fitter.step(samples, labels)
+        # the sample count over all ranks is known statically: no count all-reduce, no host sync in the step
+        gb = self.global_batch if self.global_batch is not None else self.fitter.world_size() * eng.B
+        return self.fitter.step(samples, labels, global_count=gb * self.sampler.S)
 
     def step(self, t=None, want_terms=False):
         if self.checker is not None and self.step_count % self.fit_freq == 0:

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, static_count):
     for p in (ROOT, os.path.join(ROOT, "pytorch-motion-planner_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -62,7 +62,9 @@ def _worker(rank, world, port, out_dir):
     lo, hi = nfopp.shard_range(total, rank, world)       # uneven split: 209 samples over 2 ranks
     x = torch.tensor(z["x"][lo:hi].astype(np.float32))
     y = torch.tensor(z["labels"][lo:hi].astype(np.float32))
-    loss = fitter.step(x, y, adam_fn=adam_fn)
+    # static_count: the caller states the global sample count (BatchPlanner's hot loop: no count all-reduce, no host
+    # sync); otherwise the fitter asks the group for it
+    loss = fitter.step(x, y, adam_fn=adam_fn, global_count=total if static_count else None)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), params=onf.flat_parameters.numpy(), loss=float(loss),
              count=float(fitter.grad[-1]), grad=fitter.grad[:-2].numpy())
     dist.barrier()
@@ -70,9 +72,10 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_data_parallel_onf_fit_equals_single_process(tmp_path):
+@pytest.mark.parametrize("static_count", [True, False])
+def test_data_parallel_onf_fit_equals_single_process(tmp_path, static_count):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), static_count), nprocs=world, join=True)
     z = np.load(os.path.join(GOLDEN, "g7_onf_train.npz"))
     r0, r1 = (np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(world))
     assert np.array_equal(r0["params"], r1["params"])                       # replicas stay bit-identical

@@ -8,7 +8,7 @@ cd /tmp
 rocprofv3 -L > $R/gpurun_out/pmc/counters_list.txt 2>&1 || true
 run() {  # name, counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$name -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-sample 0 --fit-iters 20 --spin-up 0 > $R/gpurun_out/pmc/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $R/gpurun_out/pmc/$name.log; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$name -- python3 $R/bench.py --matrix-path fp32 --steps 6 --warmup 2 --cpu-sample 0 --fit-iters 20 --spin-up 0 > $R/gpurun_out/pmc/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $R/gpurun_out/pmc/$name.log; }
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
