@@ -23,7 +23,7 @@ namespace nfopp {
 // MODE 0: forward + input gradient (planner step)   1: training pass (factor matrices for the weight gradients)
 // MODE 2: forward only (logits: pool-candidate weights, `ONF.forward`)
 template <int NKT, int NT, int MODE>
-__global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernelArgs a) {
+__global__ __launch_bounds__(THREADS, THREADS / 256) void onf_fwd_bwd_kernel(const OnfKernelArgs a) {
   constexpr bool TRAIN = MODE == 1;
   constexpr bool FWD_ONLY = MODE == 2;
   using L = Lds<NKT>;
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
   constexpr int WIN = 16 * NKT;   // row length of the input-side factor matrices (TRAIN)
   constexpr int WH = 16 * HT;     // row length of the hidden-side factor matrices
   float loss_acc = 0.f;
+  f32x4 g4_acc[HT];   // TRAIN: running sum_p rho_p * relu(a2_p) of this lane's (hidden row, point column) cells
+#pragma unroll
+  for (int mt = 0; mt < HT; ++mt) g4_acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // ---------------------------------------------------------------- sample / load the wave's points
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
       uy[tl] = (y - geo.mean) / geo.sigma;
       th[tl] = ang;
       if (TRAIN && g == 0 && pidx[tl] < a.n_points)
-        *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 4) = f32x4{ux[tl], uy[tl], 1.0f, ang};
+        *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 12) = f32x4{ux[tl], uy[tl], 1.0f, ang};
     }
 
     // ---------------------------------------------------------------- L1: a1 = W1 in + b1, features just-in-time
@@ -124,13 +127,6 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
           skip[0] = fmaf(eb[10], v.y, skip[0]);
           fv[r][0] = v.x; fv[r + 1][0] = v.y;
         }
-      }
-      if (TRAIN) {
-#pragma unroll
-        for (int tl = 0; tl < NT; ++tl)
-          if (pidx[tl] < a.n_points)
-            *reinterpret_cast<f32x4*>(a.ws_in + pidx[tl] * WIN + 16 * kt + 4 * g) =
-                f32x4{fv[0][tl], fv[1][tl], fv[2][tl], fv[3][tl]};
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -198,18 +194,6 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
     }
 
     // ---------------------------------------------------------------- logit and dh2 = W3a * [a2 > 0]
-    if (TRAIN) {
-#pragma unroll
-      for (int tl = 0; tl < NT; ++tl)
-        if (pidx[tl] < a.n_points) {
-#pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            f32x4 v = {relu1(acc2[tl][t][0]), relu1(acc2[tl][t][1]), relu1(acc2[tl][t][2]), relu1(acc2[tl][t][3])};
-            if (t == 6) v = f32x4{v[0], 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(a.ws_h2 + pidx[tl] * WH + 16 * t + 4 * g) = v;
-          }
-        }
-    }
     float logit[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) logit[tl] = skip[tl];
@@ -223,7 +207,7 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
           const float a2 = acc2[tl][mt][r];
           const float d2 = a2 > 0.0f ? w3a[r] : 0.0f;   // dh2 = W3a * [a2 > 0]
           logit[tl] = fmaf(d2, a2, logit[tl]);          // = W3a * relu(a2)
-          acc2[tl][mt][r] = d2;
+          if (!TRAIN) acc2[tl][mt][r] = d2;             // TRAIN keeps a2 until rho is known (dW3[:100] below)
         }
       }
     }
@@ -242,15 +226,24 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
         const float lp = fmaxf(l, 0.0f) - l * y + log1pf(expf(-fabsf(l)));
         rho[tl] = valid ? (1.0f / (1.0f + expf(-l)) - y) * a.inv_count : 0.0f;
         if (valid && g == 0) loss_acc += lp * a.inv_count;
+        // dW3[:100] += rho * relu(a2) (per-lane running sums, reduced over the wave's point lanes at the end); the
+        // sign pattern of a2 is all pass 2 needs to rebuild dh2 = rho * W3a * [a2 > 0]; then acc2 <- dh2
+        unsigned a2_mask = 0;
 #pragma unroll
-        for (int mt = 0; mt < HT; ++mt) acc2[tl][mt] = acc2[tl][mt] * rho[tl];
-        if (valid) {
+        for (int mt = 0; mt < HT; ++mt) {
+          const f32x4 w3a = *reinterpret_cast<const f32x4*>(lds + L::W3A + (mt < 6 ? base_p(mt) + colP : 96 + 4 * g));
 #pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            f32x4 v = acc2[tl][t];
-            if (t == 6) v = f32x4{v[0], g == 0 ? rho[tl] : 0.0f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(a.ws_dh2 + pidx[tl] * WH + 16 * t + 4 * g) = v;
+          for (int r = 0; r < 4; ++r) {
+            const float a2 = acc2[tl][mt][r];
+            const bool on = a2 > 0.0f;
+            g4_acc[mt][r] = fmaf(rho[tl], relu1(a2), g4_acc[mt][r]);
+            a2_mask |= (on ? 1u : 0u) << (4 * mt + r);
+            acc2[tl][mt][r] = (on ? w3a[r] : 0.0f) * rho[tl];
           }
+        }
+        if (valid) {
+          if (g == 0) *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 12 + 4) = f32x4{rho[tl], 0.f, 0.f, 0.f};
+          reinterpret_cast<unsigned*>(a.ws_u)[pidx[tl] * 12 + 8 + g] = a2_mask;
         }
       }
     }
@@ -414,6 +407,17 @@ __global__ __launch_bounds__(THREADS, 2) void onf_fwd_bwd_kernel(const OnfKernel
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o);
     if (lane == 0) a.loss_partial[blockIdx.x * WAVES + wave] = loss_acc;
+    // dW3[:100] partial of this wave: sum over its 16 point lanes (xor tree, fixed order), h2 slot = 16 mt + 4 g + r
+    float* g4 = a.g4_partial + (size_t)(blockIdx.x * WAVES + wave) * (16 * HT);
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      f32x4 v = g4_acc[mt];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], o);
+      if (i == 0) *reinterpret_cast<f32x4*>(g4 + 16 * mt + 4 * g) = v;
+    }
   }
 }
 

@@ -22,18 +22,18 @@ struct OnfKernelArgs {
   // The kernel then walks live[0] * (n_way - 1) samples; t / out4 rows keep their place (trajectory * (n_way-1) + j).
   const int* live;
   float* out4;
-  // training mode (TRAIN kernels only): labels, BCE normalisation, per-sample factor matrices for the weight-gradient
-  // GEMMs (csrc/onf_wgrad.hip), per-wave loss partials
+  // training mode (TRAIN kernels only): labels, BCE normalisation, the per-sample factors the weight-gradient GEMMs
+  // (csrc/onf_wgrad.hip) cannot rebuild cheaply, per-wave loss and dW3[:100] partials.  NOT stored (rebuilt in pass 2
+  // from the 48-byte record): the input features `in` (a function of u) and dh2 (= rho * W3a * [a2 > 0]); h2 never
+  // leaves the kernel (its only use, dW3[:100] = sum_p rho_p h2_p, is accumulated here).
   const float* labels;
   float inv_count;
   int aug_feature;   // zero-weight pad feature evaluated as cos(0) = 1: the "ones" column of the input matrix
-  float* ws_in;      // [P, 16*NKT]   input features in slot order, ones column at the slot of aug_feature
   float* ws_h1;      // [P, 112]      relu(a1) in slot order (layout Q), ones at slot 16*6 + 1
-  float* ws_h2;      // [P, 112]      relu(a2) (layout P)
   float* ws_dh1;     // [P, 112]      d loss / d a1, rho at slot 16*6 + 1
-  float* ws_dh2;     // [P, 112]      d loss / d a2, rho at slot 16*6 + 1
   float* ws_de;      // [P, 16*NKT]   d loss / d (encoding argument)
-  float* ws_u;       // [P, 4]        (ux, uy, 1, theta)
+  float* ws_u;       // [P, 12]       (ux, uy, 1, theta | rho, 0, 0, 0 | 4 words: bit 4*tile + r of word g = [a2 > 0])
+  float* g4_partial; // [grid * WAVES, 112]  per-wave sum_p rho_p * relu(a2_p) in h2 slot order (layout P)
   float* loss_partial;  // [grid * WAVES]
 };
 

@@ -12,7 +12,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int H = NFOPP_HIDDEN;
 constexpr int HT = 7;     // hidden tiles of 16 (tile 6 carries features 96..99 in rows (g, r = 0))
 constexpr int S2 = 129;   // LDS row stride of W2 (floats), = 1 mod 32
-constexpr int THREADS = 512;
+#ifndef NFOPP_THREADS
+#define NFOPP_THREADS 512   /* development: 256 = one wave per SIMD (tools/split_speed.py A/B) */
+#endif
+constexpr int THREADS = NFOPP_THREADS;
 constexpr int WAVES = THREADS / 64;
 constexpr int KSTEPS = 25;  // hidden k-steps: ks -> tile ks>>2, register ks&3 (tile 6 only register 0)
 

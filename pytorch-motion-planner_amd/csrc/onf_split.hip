@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void split_prep_kernel(const OnfGeom geo, const
 
 // MODE 0: forward + input gradient (planner step)   2: forward only (logits)
 template <int NKT, int NT, int MODE>
-__global__ __launch_bounds__(THREADS, 2) void onf_split_kernel(const OnfKernelArgs a, const u32x4* __restrict__ blob) {
+__global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const OnfKernelArgs a, const u32x4* __restrict__ blob) {
   static_assert(MODE == 0 || MODE == 2, "the training pass stays on the fp32 kernel");
   constexpr bool FWD_ONLY = MODE == 2;
   using L = Lds<NKT>;
@@ -994,7 +994,11 @@ static int launch_split_t(const OnfKernelArgs& a, hipStream_t stream) {
 template <int MODE>
 static int launch_split_mode(const OnfKernelArgs& a, hipStream_t stream) {
   const int nkt = (a.geom.fin + 15) / 16;
+#ifdef NFOPP_FORCE_NT1
+  const bool small = true;   // development A/B: one point tile per wave at any size
+#else
   const bool small = a.n_points < (long long)query_cus() * WAVES * 16 * 2;
+#endif
   switch (nkt) {
     case 14: return small ? launch_split_t<14, 1, MODE>(a, stream) : launch_split_t<14, 2, MODE>(a, stream);
     case 13: return small ? launch_split_t<13, 1, MODE>(a, stream) : launch_split_t<13, 2, MODE>(a, stream);

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void onf_train_final_kernel(const ReduceArgs a
 using namespace nfopp;
 
 static const long long MFMA_PATH_MIN_SAMPLES = 2048;  // below this the per-sample path is launch-bound anyway
+static const long long PER_SAMPLE_MAX = 65536;        // largest fit the per-sample path is budgeted for (path = 1 on request)
 
 static int train_grad_per_sample(const OnfGeom& g, const float* params_dev, const float* samples_dev,
                                  const float* labels_dev, int64_t n_samples, float inv_count, float* grad_dev,
@@ -236,8 +237,11 @@ static int train_grad_per_sample(const OnfGeom& g, const float* params_dev, cons
 extern "C" size_t nfopp_onf_train_workspace_bytes(const nfopp_onf_config* cfg, int64_t n_samples) {
   OnfGeom g;
   if (!make_geom(cfg, &g) || n_samples < 0) return 0;
-  const size_t a = (size_t)carve(g, n_samples).total * sizeof(float);
+  // the per-sample path keeps 3.5 KB per sample: it serves small fits (and, on request, up to PER_SAMPLE_MAX samples);
+  // beyond that only the MFMA path's compact factors (1.84 KB per sample) are budgeted
   const size_t b = wgrad_workspace_bytes(g, n_samples);
+  if (n_samples > PER_SAMPLE_MAX) return b;
+  const size_t a = (size_t)carve(g, n_samples).total * sizeof(float);
   return a > b ? a : b;
 }
 
@@ -250,6 +254,8 @@ extern "C" int nfopp_onf_train_grad_ex(const nfopp_onf_config* cfg, const float*
   NFOPP_REQUIRE(params_dev && samples_dev && labels_dev && grad_dev && workspace_dev, "null device pointer");
   NFOPP_REQUIRE(n_samples > 0 && n_samples <= 0x7fffffffLL, "sample count out of range");
   NFOPP_REQUIRE(path >= 0 && path <= 2, "path must be 0 (auto), 1 (per-sample) or 2 (MFMA)");
+  NFOPP_REQUIRE(path != 1 || n_samples <= PER_SAMPLE_MAX, "the per-sample path takes at most %lld samples",
+                (long long)PER_SAMPLE_MAX);
   NFOPP_REQUIRE(workspace_bytes >= nfopp_onf_train_workspace_bytes(cfg, n_samples),
                 "workspace too small: %zu < %zu bytes", workspace_bytes, nfopp_onf_train_workspace_bytes(cfg, n_samples));
   const bool mfma = path == 2 || (path == 0 && n_samples >= MFMA_PATH_MIN_SAMPLES);

@@ -5,63 +5,105 @@
 // P = B * (N + 109) samples per step, BASELINE config 5).  Small P keeps the per-sample path of csrc/onf_train.hip.
 //
 // Pipeline (all reductions in a fixed order -> bitwise reproducible, no float atomics):
-//   1. onf_fwd_bwd_kernel<.., TRAIN> (csrc/onf_fused.hip): forward + backward per sample on the MFMA chain, writes the
-//      per-sample factor matrices  in | h1 | h2 | dh1 | dh2 | de | u  (slot order, with a ones column and a rho row so
-//      that bias and W3 gradients fall out of the same GEMMs) and per-wave loss partials;
+//   1. onf_fwd_bwd_kernel<.., TRAIN> (csrc/onf_fused.hip): forward + backward per sample on the MFMA chain.  It writes
+//      only the factors pass 2 cannot rebuild cheaply --  h1 | dh1 | de  (slot order, with a ones column and a rho row
+//      so that bias and W3 gradients fall out of the same GEMMs) and a 48-byte record (u, rho, sign bits of a2) -- plus
+//      per-wave loss partials and per-wave partials of dW3[:100] = sum_p rho_p h2_p (h2 never leaves that kernel);
+//      1.84 KB per sample instead of the 3.6 KB of a full factor dump;
 //   2. onf_wgrad_kernel: persistent workgroups, 16-sample chunks staged into LDS as one combined row per sample
-//      (stride = 16 mod 32 -> conflict-free operand reads), 8*NKT+56 output tiles spread over 8 waves:
-//        G1 = dh1^T in   (dW1, db1, dW3[100:], db3)     G2 = dh2^T h1 (dW2, db2)
-//        G3 = de^T  u    (dWe, dbe, angle grads)        G4 = rho^T h2 (dW3[:100])
+//      (stride = 16 mod 32 -> conflict-free operand reads); the input features `in` are RE-EVALUATED from u (same
+//      arithmetic as pass 1) and dh2 = rho * W3a * [a2 > 0] is rebuilt from the record; 8*NKT+49 output tiles over 8 waves:
+//        G1 = dh1^T in   (dW1, db1, dW3[100:], db3)     G2 = dh2^T h1 (dW2, db2)     G3 = de^T u (dWe, dbe, angle grads)
 //      next chunk prefetched into registers while the current one multiplies; per-workgroup partial tiles to HBM;
-//   3. onf_wgrad_reduce_kernel (sum over workgroups) and onf_wgrad_gather_kernel (slot -> parameter index).
-#include "onf_kernel.h"
+//   3. onf_wgrad_reduce_kernel (sum over workgroups / waves) and onf_wgrad_gather_kernel (slot -> parameter index).
+#include "onf_layout.h"
 
 namespace nfopp {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_THREADS = 512;
 constexpr int WG_WAVES = 8;
 constexpr int KC = 16;  // samples per LDS chunk (4 k-steps: every operand offset stays a ds_read immediate)
 constexpr int HS = 112; // hidden-side row length (7 tiles)
 
+// out[e] = sum over rows of partial[row][e] for MANY rows (per-wave partials): one block per element; thread t adds rows
+// t, t + 256, ... in ascending order, then a fixed binary tree over the 256 threads.  Deterministic for a given row count.
+__global__ __launch_bounds__(256) void onf_rows_reduce_kernel(const float* partial, float* out, int n_elems, int n_rows) {
+  __shared__ float tree[256];
+  const int e = blockIdx.x, t = threadIdx.x;
+  float s = 0.f;
+  for (int r = t; r < n_rows; r += 256) s += partial[(long long)r * n_elems + e];
+  tree[t] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) tree[t] += tree[t + o];
+    __syncthreads();
+  }
+  if (t == 0) out[e] = tree[0];
+}
+
+// ---- slot maps (see csrc/onf_fused.hip for the layouts) --------------------------------------------------------
+__host__ __device__ inline int slot_layout_p(int f) {  // input features, h2 / dh2 (features < 96)
+  const int o = f & 31, tpar = (o >> 3) & 1, op = o - 8 * tpar, ap = op & ~3, r = op & 3;
+  const int g = ((ap >> 4) & 1) | (((ap >> 2) & 1) << 1);
+  return 16 * (2 * (f >> 5) + tpar) + 4 * g + r;
+}
+__host__ __device__ inline int slot_layout_q(int f) {  // h1 / dh1 (features < 96)
+  const int o = f & 15, aq = o & 12, r = o & 3;
+  const int g = ((aq >> 3) & 1) | (((aq >> 2) & 1) << 1);
+  return 16 * (f >> 4) + 4 * g + r;
+}
+__host__ __device__ inline int hidden_slot(int h, bool layout_q) {
+  if (h >= 96) return 96 + 4 * (h - 96);
+  return layout_q ? slot_layout_q(h) : slot_layout_p(h);
+}
+constexpr int AUG_HIDDEN_SLOT = 97;  // tile 6, g = 0, r = 1
+
 template <int NKT>
 struct WgLayout {
   static constexpr int WIN = 16 * NKT;
-  static constexpr int C_DH1 = 0, C_IN = HS, C_DH2 = C_IN + WIN, C_H1 = C_DH2 + HS, C_DE = C_H1 + HS,
-                       C_U = C_DE + WIN, C_H2 = C_U + 16, STRIDE = C_H2 + HS;  // = 464 + 2*WIN = 16 mod 32
-  static constexpr int NTILES = 8 * NKT + 56;
+  // combined LDS row of one sample; +16 pad keeps the stride = 16 mod 32
+  static constexpr int C_DH1 = 0, C_IN = HS, C_DH2 = C_IN + WIN, C_H1 = C_DH2 + HS, C_DE = C_H1 + HS, C_U = C_DE + WIN,
+                       STRIDE = C_U + 16 + 16;
+  static_assert(STRIDE % 32 == 16, "operand reads are conflict-free for a row stride of 16 mod 32");
+  static constexpr int NTILES = 8 * NKT + 49;
   static constexpr int TPW = (NTILES + WG_WAVES - 1) / WG_WAVES;  // tiles per wave
-  static constexpr int F4_PER_SAMPLE = (4 * HS + 2 * WIN + 4) / 4;
+  static constexpr int F4_PER_SAMPLE = (2 * HS + WIN + 12) / 4;    // stored: dh1 | h1 | de | record
   static constexpr int F4_PER_THREAD = (KC * F4_PER_SAMPLE + WG_THREADS - 1) / WG_THREADS;
-  static constexpr size_t LDS_BYTES = size_t(KC) * STRIDE * 4;
+  static constexpr int REBUILD_F4 = (HS + WIN) / 4;                // rebuilt per sample: dh2 | in
+  // LDS: two buffers of { KC combined rows | record tail: rho [KC], a2 sign words [KC][4] } (chunk k multiplies from
+  //      one while chunk k+1 is committed and rebuilt in the other) | feature table as six planes [6][WIN] (wx | wy | b | fr | qh | is_angle,
+  //      slot order: a lane reads four consecutive slots of a plane with ONE 16-byte access) | W3a [HS] (slot order)
+  static constexpr int B_RHO = KC * STRIDE, B_MASK = B_RHO + KC, BUF = B_MASK + 4 * KC;
+  static constexpr int L_FT = 2 * BUF, L_W3A = L_FT + 6 * WIN, L_TOTAL = L_W3A + HS;
+  static constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 };
 
 struct WgradArgs {
-  // factor matrices, stored back to back in this order (carve_wgrad):  in [P,WIN] | h1 | h2 | dh1 | dh2 [P,112 each] |
-  // de [P,WIN] | u [P,4]  -- so every array starts at P * (compile-time floats-per-sample prefix)
+  OnfGeom geom;
+  const float* params;
+  int aug_feature;
+  // stored factors, back to back in this order (carve_wgrad):  h1 [P,112] | dh1 [P,112] | de [P,WIN] | record [P,12]
   const float* ws;
   long long P;
   float* partial;  // [grid][NTILES][256]
 };
 
 // float4 number c (0 .. F4_PER_SAMPLE) of a sample: workspace offset of its source and its column in the combined LDS
-// row.  Branch-free selects over compile-time constants, because the lanes of a wave straddle the segment boundaries.
+// row (col < 0: record words 4..11 -> rho / sign-bit arrays).  Branch-free selects over compile-time constants, because
+// the lanes of a wave straddle the segment boundaries.
 template <int NKT>
 __device__ __forceinline__ void f4_source(long long P, long long p, int c, long long* src_off, int* col) {
   using W = WgLayout<NKT>;
   constexpr int h4 = HS / 4, w4 = W::WIN / 4;
-  constexpr int t1 = h4, t2 = t1 + w4, t3 = t2 + h4, t4 = t3 + h4, t5 = t4 + w4, t6 = t5 + 1;
+  constexpr int t1 = h4, t2 = t1 + h4, t3 = t2 + w4;
   // (prefix = floats per sample stored before this array, row length, first c, LDS column)
-  int prefix = W::WIN + 2 * HS, row = HS, start = 0, lcol = W::C_DH1;                       // dh1
-  if (c >= t1) { prefix = 0; row = W::WIN; start = t1; lcol = W::C_IN; }                     // in
-  if (c >= t2) { prefix = W::WIN + 3 * HS; row = HS; start = t2; lcol = W::C_DH2; }          // dh2
-  if (c >= t3) { prefix = W::WIN; row = HS; start = t3; lcol = W::C_H1; }                    // h1
-  if (c >= t4) { prefix = W::WIN + 4 * HS; row = W::WIN; start = t4; lcol = W::C_DE; }       // de
-  if (c >= t5) { prefix = 2 * W::WIN + 4 * HS; row = 4; start = t5; lcol = W::C_U; }         // u
-  if (c >= t6) { prefix = W::WIN + HS; row = HS; start = t6; lcol = W::C_H2; }               // h2
+  int prefix = HS, row = HS, start = 0, lcol = W::C_DH1;                                  // dh1
+  if (c >= t1) { prefix = 0; row = HS; start = t1; lcol = W::C_H1; }                       // h1
+  if (c >= t2) { prefix = 2 * HS; row = W::WIN; start = t2; lcol = W::C_DE; }              // de
+  if (c >= t3) { prefix = 2 * HS + W::WIN; row = 12; start = t3; lcol = W::C_U; }          // record: u | rho | sign words
   *src_off = P * prefix + p * row + 4 * (c - start);
   *col = lcol + 4 * (c - start);
+  if (c > t3) *col = -(c - t3);   // -1: rho quad, -2: the four sign words
 }
 
 template <int NKT>
@@ -83,8 +125,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
     int ac, bc;
     if (T < 7 * NKT) { ac = W::C_DH1 + 16 * (T / NKT); bc = W::C_IN + 16 * (T % NKT); }
     else if (T < 7 * NKT + 49) { const int q = T - 7 * NKT; ac = W::C_DH2 + 16 * (q / 7); bc = W::C_H1 + 16 * (q % 7); }
-    else if (T < 8 * NKT + 49) { ac = W::C_DE + 16 * (T - 7 * NKT - 49); bc = W::C_U; }
-    else { ac = W::C_DH2 + 96; bc = W::C_H2 + 16 * (T - 8 * NKT - 49); }
+    else { ac = W::C_DE + 16 * (T - 7 * NKT - 49); bc = W::C_U; }
     pa[j] = g * W::STRIDE + ac + i;
     pb[j] = g * W::STRIDE + bc + i;
   }
@@ -92,8 +133,38 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
 #pragma unroll
   for (int j = 0; j < W::TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // zero the unused columns 4..15 of the u tile once
-  for (int k = tid; k < KC * 12; k += WG_THREADS) lds[(k / 12) * W::STRIDE + W::C_U + 4 + (k % 12)] = 0.0f;
+  // zero the unused columns 4..15 of the u tile once (both buffers)
+  for (int k = tid; k < 2 * KC * 12; k += WG_THREADS)
+    lds[(k / (KC * 12)) * W::BUF + ((k / 12) % KC) * W::STRIDE + W::C_U + 4 + (k % 12)] = 0.0f;
+  // tables in SLOT order for the rebuilt factors: feature table of `in` (pads evaluate to sin(0) = 0, the pad feature
+  // `aug_feature` to cos(0) = 1: the ones column, as in fill_lds) and W3a for dh2
+  {
+    const OnfGeom& g = a.geom;
+    const float* P = a.params;
+    for (int k = tid; k < 6 * W::WIN; k += WG_THREADS) lds[W::L_FT + k] = 0.0f;
+    for (int k = tid; k < HS; k += WG_THREADS) lds[W::L_W3A + k] = 0.0f;
+    __syncthreads();
+    for (int f = tid; f < 32 * ((NKT + 1) / 2); f += WG_THREADS) {
+      const int slot = slot_layout_p(f);
+      if (slot >= W::WIN) continue;
+      float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, qh = 0.f, isa = 0.f;
+      if (f < g.n_enc) {
+        wx = P[g.off_we + 2 * f]; wy = P[g.off_we + 2 * f + 1];
+        b = g.off_be >= 0 ? P[g.off_be + f] : 0.0f;
+        qh = (g.n_enc > g.n_sin && f >= g.n_sin) ? NFOPP_Q_UNIT : 0.0f;
+      } else if (f < g.fin) {
+        const int k = f - g.n_enc;
+        b = P[g.off_ang_b + k]; fr = P[g.off_ang_f + k];
+        qh = k >= g.ang_dim ? NFOPP_Q_UNIT : 0.0f;
+        isa = 1.0f;
+      } else if (f == a.aug_feature) {
+        qh = NFOPP_Q_UNIT;
+      }
+      float* e = lds + W::L_FT + slot;
+      e[0] = wx; e[W::WIN] = wy; e[2 * W::WIN] = b; e[3 * W::WIN] = fr; e[4 * W::WIN] = qh; e[5 * W::WIN] = isa;
+    }
+    for (int h = tid; h < NFOPP_HIDDEN; h += WG_THREADS) lds[W::L_W3A + hidden_slot(h, false)] = P[g.off_w3 + h];
+  }
 
   f32x4 stage[W::F4_PER_THREAD];
   auto prefetch = [&](long long chunk) {
@@ -113,7 +184,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
       stage[k] = v;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](float* buf) {
 #pragma unroll
     for (int k = 0; k < W::F4_PER_THREAD; ++k) {
       const int idx = tid + k * WG_THREADS;
@@ -121,18 +192,69 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
         const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
         long long src; int col;
         f4_source<NKT>(0, 0, c, &src, &col);
-        *reinterpret_cast<f32x4*>(lds + q * W::STRIDE + col) = stage[k];
+        if (col >= 0) *reinterpret_cast<f32x4*>(buf + q * W::STRIDE + col) = stage[k];
+        else if (col == -1) buf[W::B_RHO + q] = stage[k][0];
+        else *reinterpret_cast<f32x4*>(buf + W::B_MASK + 4 * q) = stage[k];
+      }
+    }
+  };
+  // factors pass 1 did not store: in = features(u) with pass 1's arithmetic (features2), dh2 = rho * W3a * [a2 > 0]
+  auto rebuild = [&](float* buf) {
+    for (int idx = tid; idx < KC * W::REBUILD_F4; idx += WG_THREADS) {
+      const int q = idx / W::REBUILD_F4, c = idx - q * W::REBUILD_F4;
+      float* row = buf + q * W::STRIDE;
+      if (c < HS / 4) {                       // dh2 slots 4c .. 4c+3: tile c >> 2, lane group c & 3
+        const unsigned bits = __float_as_uint(buf[W::B_MASK + 4 * q + (c & 3)]) >> (4 * (c >> 2));
+        const float rho = buf[W::B_RHO + q];
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + W::L_W3A + 4 * c);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((bits >> r) & 1u) ? w[r] * rho : 0.0f;
+        *reinterpret_cast<f32x4*>(row + W::C_DH2 + 4 * c) = v;
+      } else {                                // in slots 4s .. 4s+3
+        const int s4 = c - HS / 4;
+        const f32x2 ux = splat2(row[W::C_U]), uy = splat2(row[W::C_U + 1]), th = splat2(row[W::C_U + 3]);
+        const float* e = lds + W::L_FT + 4 * s4;
+        const f32x4 wx = *reinterpret_cast<const f32x4*>(e), wy = *reinterpret_cast<const f32x4*>(e + W::WIN);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(e + 2 * W::WIN), fr = *reinterpret_cast<const f32x4*>(e + 3 * W::WIN);
+        const f32x4 qh = *reinterpret_cast<const f32x4*>(e + 4 * W::WIN), isa = *reinterpret_cast<const f32x4*>(e + 5 * W::WIN);
+        f32x4 v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 o = features2<true, false>(f32x2{wx[2 * h], wx[2 * h + 1]}, f32x2{wy[2 * h], wy[2 * h + 1]},
+                                                 f32x2{bb[2 * h], bb[2 * h + 1]}, f32x2{fr[2 * h], fr[2 * h + 1]},
+                                                 f32x2{qh[2 * h], qh[2 * h + 1]}, f32x2{isa[2 * h], isa[2 * h + 1]}, ux, uy, th);
+          v[2 * h] = o.x; v[2 * h + 1] = o.y;
+        }
+        *reinterpret_cast<f32x4*>(row + W::C_IN + 4 * s4) = v;
       }
     }
   };
 
-  long long chunk = blockIdx.x;
-  if (chunk < n_chunks) prefetch(chunk);
-  for (; chunk < n_chunks; chunk += gridDim.x) {
-    __syncthreads();  // previous chunk fully consumed
-    commit();
+  // Pipeline over this workgroup's chunks c0, c0 + grid, ...: while chunk k multiplies out of one LDS buffer, chunk k+1 is
+  // committed (registers -> LDS) and rebuilt in the other, and chunk k+2 is in flight from HBM.  Two barriers per chunk;
+  // between them a wave either rebuilds or multiplies, so the rebuild arithmetic of one wave overlaps the MFMAs of
+  // the others.
+  const long long c0 = blockIdx.x, step = gridDim.x;
+  float* cur = lds;
+  float* nxt = lds + W::BUF;
+  if (c0 < n_chunks) {
+    prefetch(c0);
+    commit(cur);
+    if (c0 + step < n_chunks) prefetch(c0 + step);
     __syncthreads();
-    if (chunk + gridDim.x < n_chunks) prefetch(chunk + gridDim.x);
+    rebuild(cur);
+  }
+  for (long long chunk = c0; chunk < n_chunks; chunk += step) {
+    const bool has_next = chunk + step < n_chunks;
+    if (has_next) commit(nxt);                               // staged registers of chunk + step
+    if (chunk + 2 * step < n_chunks) prefetch(chunk + 2 * step);
+    __syncthreads();                                          // `cur` rebuilt by everyone, `nxt` committed by everyone
+#ifndef NFOPP_ABL_NO_REBUILD
+    if (has_next) rebuild(nxt);
+#endif
+    const int off = (int)(cur - lds);
+#ifndef NFOPP_ABL_NO_MFMA
     constexpr int GRP = 7;  // tiles whose operands are in flight together
 #pragma unroll
     for (int j0 = 0; j0 < W::TPW; j0 += GRP) {
@@ -141,8 +263,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
         float av[GRP], bv[GRP];
 #pragma unroll
         for (int j = j0; j < j0 + GRP && j < W::TPW; ++j) {
-          av[j - j0] = lds[pa[j] + 4 * s * W::STRIDE];
-          bv[j - j0] = lds[pb[j] + 4 * s * W::STRIDE];
+          av[j - j0] = lds[off + pa[j] + 4 * s * W::STRIDE];
+          bv[j - j0] = lds[off + pb[j] + 4 * s * W::STRIDE];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -151,6 +273,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#endif
+    __syncthreads();                                          // `cur` consumed, `nxt` rebuilt
+    float* t = cur; cur = nxt; nxt = t;
   }
 #pragma unroll
   for (int j = 0; j < W::TPW; ++j) {
@@ -172,28 +297,12 @@ __global__ __launch_bounds__(256) void onf_wgrad_reduce_kernel(const float* part
   reduced[e] = s;
 }
 
-// ---- slot maps (see csrc/onf_fused.hip for the layouts) --------------------------------------------------------
-__host__ __device__ inline int slot_layout_p(int f) {  // input features, h2 / dh2 (features < 96)
-  const int o = f & 31, tpar = (o >> 3) & 1, op = o - 8 * tpar, ap = op & ~3, r = op & 3;
-  const int g = ((ap >> 4) & 1) | (((ap >> 2) & 1) << 1);
-  return 16 * (2 * (f >> 5) + tpar) + 4 * g + r;
-}
-__host__ __device__ inline int slot_layout_q(int f) {  // h1 / dh1 (features < 96)
-  const int o = f & 15, aq = o & 12, r = o & 3;
-  const int g = ((aq >> 3) & 1) | (((aq >> 2) & 1) << 1);
-  return 16 * (f >> 4) + 4 * g + r;
-}
-__host__ __device__ inline int hidden_slot(int h, bool layout_q) {
-  if (h >= 96) return 96 + 4 * (h - 96);
-  return layout_q ? slot_layout_q(h) : slot_layout_p(h);
-}
-constexpr int AUG_HIDDEN_SLOT = 97;  // tile 6, g = 0, r = 1
-
 struct GatherArgs {
   OnfGeom geom;
   int nkt, aug_in_slot, n_loss_partials;
   const float* params;
   const float* reduced;       // [NTILES][256]
+  const float* g4;            // [112] dW3[:100] in h2 slot order (reduced per-wave partials of pass 1)
   const float* loss_partial;
   float* grad;                // [n_params + 2]
   float count;
@@ -207,7 +316,7 @@ __global__ __launch_bounds__(256) void onf_wgrad_gather_kernel(const GatherArgs 
   const OnfGeom& g = a.geom;
   const int NKT = a.nkt;
   const int o = blockIdx.x * 256 + threadIdx.x;
-  const int T_G2 = 7 * NKT, T_G3 = 7 * NKT + 49, T_G4 = 8 * NKT + 49;
+  const int T_G2 = 7 * NKT, T_G3 = 7 * NKT + 49;
   if (o < g.n_params) {
     float v = 0.f;
     if (g.n_ang && o < g.off_ang_b + g.n_ang) {            // d/d angle bias = f_k * sum dz_k
@@ -234,8 +343,7 @@ __global__ __launch_bounds__(256) void onf_wgrad_gather_kernel(const GatherArgs 
     } else if (o < g.off_b3) {                             // W3[j]
       const int j = o - g.off_w3;
       if (j < NFOPP_HIDDEN) {
-        const int cs = hidden_slot(j, false);
-        v = tile_elem(a.reduced, T_G4 + cs / 16, 1, cs % 16);
+        v = a.g4[hidden_slot(j, false)];
       } else {
         const int cs = slot_layout_p(j - NFOPP_HIDDEN);
         v = tile_elem(a.reduced, 6 * NKT + cs / 16, 1, cs % 16);
@@ -267,7 +375,7 @@ static int find_aug_feature(int fin, int nkt) {
 }
 
 struct WgradWs {  // float offsets into the workspace
-  long long in, h1, h2, dh1, dh2, de, u, loss, partial, reduced, total;
+  long long h1, dh1, de, rec, loss, g4_partial, g4, partial, reduced, total;
   int win, ntiles, grid_cap;
 };
 
@@ -275,17 +383,16 @@ static WgradWs carve_wgrad(const OnfGeom& g, long long P) {
   WgradWs w;
   const int nkt = (g.fin + 15) / 16;
   w.win = 16 * nkt;
-  w.ntiles = 8 * nkt + 56;
+  w.ntiles = 8 * nkt + 49;
   w.grid_cap = onf_train_grid_upper_bound();
   long long o = 0;
-  w.in = o; o += P * w.win;
-  w.h1 = o; o += P * HS;
-  w.h2 = o; o += P * HS;
+  w.h1 = o; o += P * HS;       // the kernel addresses these four back to back (f4_source): keep the order
   w.dh1 = o; o += P * HS;
-  w.dh2 = o; o += P * HS;
   w.de = o; o += P * w.win;
-  w.u = o; o += P * 4;
+  w.rec = o; o += P * 12;
   w.loss = o; o += (long long)w.grid_cap * 8;
+  w.g4_partial = o; o += (long long)w.grid_cap * 8 * HS;
+  w.g4 = o; o += HS;
   w.partial = o; o += (long long)w.grid_cap * w.ntiles * 256;
   w.reduced = o; o += (long long)w.ntiles * 256;
   w.total = o;
@@ -316,14 +423,15 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
   OnfKernelArgs a = {};
   a.geom = g; a.params = params; a.points = samples; a.n_points = P; a.out4 = nullptr;
   a.labels = labels; a.inv_count = inv_count; a.aug_feature = aug;
-  a.ws_in = ws + w.in; a.ws_h1 = ws + w.h1; a.ws_h2 = ws + w.h2; a.ws_dh1 = ws + w.dh1; a.ws_dh2 = ws + w.dh2;
-  a.ws_de = ws + w.de; a.ws_u = ws + w.u; a.loss_partial = ws + w.loss;
+  a.ws_h1 = ws + w.h1; a.ws_dh1 = ws + w.dh1; a.ws_de = ws + w.de; a.ws_u = ws + w.rec;
+  a.loss_partial = ws + w.loss; a.g4_partial = ws + w.g4_partial;
   int grid_fwd = 0;
   int rc = launch_onf_train_kernel(a, st, &grid_fwd);
   if (rc) return rc;
 
   WgradArgs wa;
-  wa.ws = ws + w.in; wa.P = P; wa.partial = ws + w.partial;   // arrays back to back from w.in (see carve_wgrad)
+  wa.geom = g; wa.params = params; wa.aug_feature = aug;
+  wa.ws = ws + w.h1; wa.P = P; wa.partial = ws + w.partial;   // arrays back to back from w.h1 (see carve_wgrad)
   long long n_chunks = (P + KC - 1) / KC;
   int grid = (int)(n_chunks < w.grid_cap ? n_chunks : w.grid_cap);
   switch (nkt) {
@@ -338,9 +446,12 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
   hipLaunchKernelGGL(onf_wgrad_reduce_kernel, dim3((n_elems + 255) / 256), dim3(256), 0, st, ws + w.partial,
                      ws + w.reduced, n_elems, grid);
   NFOPP_HIP(hipGetLastError());
+  // dW3[:100]: per-wave partials of pass 1, waves in launch order
+  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(HS), dim3(256), 0, st, ws + w.g4_partial, ws + w.g4, HS, grid_fwd * 8);
+  NFOPP_HIP(hipGetLastError());
   GatherArgs ga;
   ga.geom = g; ga.nkt = nkt; ga.aug_in_slot = slot_layout_p(aug); ga.n_loss_partials = grid_fwd * 8;
-  ga.params = params; ga.reduced = ws + w.reduced; ga.loss_partial = ws + w.loss; ga.grad = grad; ga.count = (float)P;
+  ga.params = params; ga.reduced = ws + w.reduced; ga.g4 = ws + w.g4; ga.loss_partial = ws + w.loss; ga.grad = grad; ga.count = (float)P;
   hipLaunchKernelGGL(onf_wgrad_gather_kernel, dim3((g.n_params + 255) / 256), dim3(256), 0, st, ga);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;

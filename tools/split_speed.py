@@ -2,8 +2,11 @@
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, "pytorch-motion-planner_amd")
+import os
 import nfopp
 from nfopp import _lib
+if os.environ.get("NFOPP_DEV_LIB"):      # A/B a development build of the library (e.g. build/v256/libnfopp_hip.so)
+    _lib.LIB_PATH = os.environ["NFOPP_DEV_LIB"]
 
 def main():
     torch.manual_seed(0)
@@ -15,12 +18,14 @@ def main():
     outs = {}
     for path in (0, 1, 0, 1):
         _lib.check(lib.nfopp_set_matrix_path(path))
+        eng.rng_offset = 0
         for _ in range(5):
             eng.collision_eval()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
+            eng.rng_offset = 0        # same draws on every call and path, so the outputs are comparable
             eng.collision_eval()
         e1.record(); torch.cuda.synchronize()
         outs[path] = eng.onf_out.clone()

@@ -6,10 +6,12 @@ for p in (ROOT, os.path.join(ROOT, "pytorch-motion-planner_amd")):
     sys.path.insert(0, p)
 import nfopp
 from nfopp import _lib
+if os.environ.get("NFOPP_DEV_LIB"):      # A/B a development build of the library
+    _lib.LIB_PATH = os.environ["NFOPP_DEV_LIB"]
 torch.random.manual_seed(1)
 onf = nfopp.ONF(0, 10, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to("cuda")
 lib = nfopp.load_library()
-for P in (262144, 1048576, 2543616):
+for P in ((2543616,) if os.environ.get("NFOPP_DEV_LIB") else (262144, 1048576, 2543616)):
     x = torch.rand(P, 3, device="cuda") * torch.tensor([100.0, 100.0, 6.28], device="cuda")
     y = (torch.rand(P, device="cuda") < 0.3).float()
     c = onf.config_c()
