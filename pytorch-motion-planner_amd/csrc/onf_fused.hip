@@ -487,6 +487,7 @@ int launch_onf_logits_kernel(const OnfKernelArgs& a, hipStream_t stream) {
 // training forward/backward pass (factor matrices for csrc/onf_wgrad.hip); one tile per wave: the factor stores
 // need the registers the second tile would take
 int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out) {
+  if (onf_split_enabled()) return launch_onf_split_train_kernel(a, stream, grid_out);
   const int nkt = (a.geom.fin + 15) / 16;
   switch (nkt) {
     case 14: return launch_t<14, 1, 1>(a, stream, grid_out);

@@ -41,6 +41,7 @@ int query_cus();
 int launch_onf_kernel(const OnfKernelArgs& a, hipStream_t stream);
 // csrc/onf_split.hip: the same kernels with every GEMM issued as bf16x3 split-precision products (mode 0 / 2)
 int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only);
+int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);
 bool onf_split_enabled();
 int launch_onf_logits_kernel(const OnfKernelArgs& a, hipStream_t stream);
 int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);

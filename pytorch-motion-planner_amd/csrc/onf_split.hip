@@ -192,15 +192,17 @@ __global__ __launch_bounds__(64) void split_prep_kernel(const OnfGeom geo, const
   blob[step * 64 + lane] = out;
 }
 
-// MODE 0: forward + input gradient (planner step)   2: forward only (logits)
+// MODE 0: forward + input gradient (planner step)   1: training pass (factors for the weight-gradient GEMMs, as
+// onf_fused.hip's TRAIN mode: same stores, same record)   2: forward only (logits)
 template <int NKT, int NT, int MODE>
 __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const OnfKernelArgs a, const u32x4* __restrict__ blob) {
-  static_assert(MODE == 0 || MODE == 2, "the training pass stays on the fp32 kernel");
   constexpr bool FWD_ONLY = MODE == 2;
+  constexpr bool TRAIN = MODE == 1;
+  static_assert(!TRAIN || NT == 1, "the training pass runs one point tile per wave");
   using L = Lds<NKT>;
   using B = Blob<NKT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds<NKT, false, true>(lds, a);
+  fill_lds<NKT, TRAIN, true>(lds, a);
   __syncthreads();
 
   const OnfGeom& geo = a.geom;
@@ -222,6 +224,11 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
   const long long n_work = work_points(a);
   const long long n_chunks = (n_work + CH - 1) / CH;
   const float b3 = a.params[geo.off_b3];
+  constexpr int WIN = 16 * NKT, WH = 16 * HT;   // row lengths of the stored factors (TRAIN)
+  float loss_acc = 0.f;
+  f32x4 g4_acc[HT];   // TRAIN: running sum_p rho_p * relu(a2_p) of this lane's (hidden row, point column) cells
+#pragma unroll
+  for (int mt = 0; mt < HT; ++mt) g4_acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // third-level fragments through a buffer resource: address = base (4 scalar registers, built once) + 16 * lane (ONE
   // vector register for the whole kernel) + the step's byte offset (a scalar operand) -- no per-step 64-bit vector
   // address, no FLAT load (which would count against lgkmcnt and stall every LDS wait on the global latency)
@@ -247,6 +254,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       ux[tl] = (x - geo.mean) / geo.sigma;
       uy[tl] = (y - geo.mean) / geo.sigma;
       th[tl] = ang;
+      if (TRAIN && g == 0 && pidx[tl] < a.n_points)
+        *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 12) = f32x4{ux[tl], uy[tl], 1.0f, ang};
     }
 
     NFOPP_TICK(0)   // sampling
@@ -471,6 +480,18 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       for (int kb = first_angle_kb; kb < B::NKB; ++kb) l1_block(std::true_type{}, kb);
     }
 
+    if (TRAIN) {  // h1 (layout Q slots), ones at slot (tile 6, g = 0, r = 1)
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl)
+        if (pidx[tl] < a.n_points) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            f32x4 v = {relu1(acc1[tl][t][0]), relu1(acc1[tl][t][1]), relu1(acc1[tl][t][2]), relu1(acc1[tl][t][3])};
+            if (t == 6) v = f32x4{v[0], g == 0 ? 1.0f : 0.0f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(a.ws_h1 + pidx[tl] * WH + 16 * t + 4 * g) = v;
+          }
+        }
+    }
     NFOPP_TICK(1)   // L1 (features + steps)
     // ---------------------------------------------------------------- L2: a2 = W2 relu(a1) + b2
     NFOPP_REDERIVE();
@@ -558,15 +579,42 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
           const float a2 = acc2[tl][mt][r];
           const float d2 = a2 > 0.0f ? w3a[r] : 0.0f;   // dh2 = W3a * [a2 > 0]
           logit[tl] = fmaf(d2, a2, logit[tl]);          // = W3a * relu(a2)
-          acc2[tl][mt][r] = d2;
+          if (!TRAIN) acc2[tl][mt][r] = d2;             // TRAIN keeps a2 until rho is known (dW3[:100] below)
         }
       }
     }
+    float rho[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
       logit[tl] += __shfl_xor(logit[tl], 16);
       logit[tl] += __shfl_xor(logit[tl], 32);
       logit[tl] += b3;
+      rho[tl] = 1.0f;
+      if (TRAIN) {   // as onf_fused.hip: BCE-with-logits (nerf:25,88), rho = (sigmoid(l) - y) / count
+        const bool valid = pidx[tl] < a.n_points;
+        const float y = valid ? a.labels[pidx[tl]] : 0.0f;
+        const float l = logit[tl];
+        const float lp = fmaxf(l, 0.0f) - l * y + log1pf(expf(-fabsf(l)));
+        rho[tl] = valid ? (1.0f / (1.0f + expf(-l)) - y) * a.inv_count : 0.0f;
+        if (valid && g == 0) loss_acc += lp * a.inv_count;
+        unsigned a2_mask = 0;
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          const f32x4 w3a = *reinterpret_cast<const f32x4*>(lds + L::W3A + (mt < 6 ? base_p(mt) + colP : 96 + 4 * g));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a2 = acc2[tl][mt][r];
+            const bool on = a2 > 0.0f;
+            g4_acc[mt][r] = fmaf(rho[tl], relu1(a2), g4_acc[mt][r]);
+            a2_mask |= (on ? 1u : 0u) << (4 * mt + r);
+            acc2[tl][mt][r] = (on ? w3a[r] : 0.0f) * rho[tl];
+          }
+        }
+        if (valid) {
+          if (g == 0) *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 12 + 4) = f32x4{rho[tl], 0.f, 0.f, 0.f};
+          reinterpret_cast<unsigned*>(a.ws_u)[pidx[tl] * 12 + 8 + g] = a2_mask;
+        }
+      }
     }
     if (FWD_ONLY) {
 #pragma unroll
@@ -662,6 +710,18 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             acc1[tl][mt][r] = ((mask1[tl] >> (4 * mt + r)) & 1u) ? accd[tl][mt][r] : 0.0f;  // dh1
+      if (TRAIN) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+          if (pidx[tl] < a.n_points) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+              f32x4 v = acc1[tl][t];
+              if (t == 6) v = f32x4{v[0], g == 0 ? rho[tl] : 0.0f, 0.f, 0.f};
+              *reinterpret_cast<f32x4*>(a.ws_dh1 + pidx[tl] * WH + 16 * t + 4 * g) = v;
+            }
+          }
+      }
     }
 
     NFOPP_TICK(4)   // L2T
@@ -711,7 +771,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
       f32x4 acc[NT];
 #pragma unroll
-      for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
+      for (int tl = 0; tl < NT; ++tl) acc[tl] = TRAIN ? w3b * rho[tl] : w3b;
       const int lo_step = B::L1T + mt * B::HKB;
 #pragma unroll
       for (int kb = 0; kb < B::HKB; ++kb) {
@@ -765,10 +825,17 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
           const f32x2 ux2 = splat2(ux[0]), uy2 = splat2(uy[0]), th2 = splat2(th[0]);
           const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, isa, ux2, uy2, th2);
           const f32x2 de = f32x2{acc[0][r], acc[0][r + 1]} * cof;
+          if (TRAIN) { acc[0][r] = de.x; acc[0][r + 1] = de.y; }
           gx[0] = fmaf(de.x, wx.x, gx[0]); gx[0] = fmaf(de.y, wx.y, gx[0]);
           gy[0] = fmaf(de.x, wy.x, gy[0]); gy[0] = fmaf(de.y, wy.y, gy[0]);
           if (ANG) { gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]); }
         }
+      }
+      if (TRAIN) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+          if (pidx[tl] < a.n_points)
+            *reinterpret_cast<f32x4*>(a.ws_de + pidx[tl] * WIN + 16 * mt + 4 * g) = acc[tl];
       }
     };
     const int first_angle_kt = 2 * first_angle_kb < NKT ? 2 * first_angle_kb : NKT;
@@ -901,6 +968,21 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
     }
     NFOPP_TICK(6)   // output
   }
+  if (TRAIN) {  // fixed-order partials, as onf_fused.hip: loss per wave, dW3[:100] per wave in h2 slot order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o);
+    if (lane == 0) a.loss_partial[blockIdx.x * WAVES + wave] = loss_acc;
+    float* g4 = a.g4_partial + (size_t)(blockIdx.x * WAVES + wave) * (16 * HT);
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) {
+      f32x4 v = g4_acc[mt];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], o);
+      if (i == 0) *reinterpret_cast<f32x4*>(g4 + 16 * mt + 4 * g) = v;
+    }
+  }
 #ifdef NFOPP_PHASE_PROFILE
   if (MODE == 0 && a.ws_u && threadIdx.x == 0)
     for (int k = 0; k < 8; ++k) atomicAdd(a.ws_u + k, phase_ticks[k]);
@@ -947,7 +1029,7 @@ static int blob_for_stream(size_t bytes, hipStream_t stream, u32x4** out) {
 }
 
 template <int NKT, int NT, int MODE>
-static int launch_split_t(const OnfKernelArgs& a, hipStream_t stream) {
+static int launch_split_t(const OnfKernelArgs& a, hipStream_t stream, int* grid_out = nullptr) {
   using L = Lds<NKT>;
   using B = Blob<NKT>;
   static bool attr_set[MAX_DEVICES] = {};
@@ -964,6 +1046,7 @@ static int launch_split_t(const OnfKernelArgs& a, hipStream_t stream) {
   long long n_chunks = (a.n_points + CH - 1) / CH;
   long long grid = query_cus();
   if (grid > n_chunks) grid = n_chunks;
+  if (grid_out) *grid_out = (int)grid;
 #ifdef NFOPP_PHASE_PROFILE
   if (MODE == 0 && NT == 2) {   // development only: synchronous, prints to stderr
     static float* dbg = nullptr;
@@ -1004,6 +1087,20 @@ static int launch_split_mode(const OnfKernelArgs& a, hipStream_t stream) {
     case 13: return small ? launch_split_t<13, 1, MODE>(a, stream) : launch_split_t<13, 2, MODE>(a, stream);
     case 8: return launch_split_t<8, 1, MODE>(a, stream);
     case 7: return launch_split_t<7, 1, MODE>(a, stream);
+    default:
+      set_error("unsupported ONF feature dimension %d", a.geom.fin);
+      return NFOPP_ERR_ARG;
+  }
+}
+
+// training pass on the split path (one point tile per wave)
+int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out) {
+  const int nkt = (a.geom.fin + 15) / 16;
+  switch (nkt) {
+    case 14: return launch_split_t<14, 1, 1>(a, stream, grid_out);
+    case 13: return launch_split_t<13, 1, 1>(a, stream, grid_out);
+    case 8: return launch_split_t<8, 1, 1>(a, stream, grid_out);
+    case 7: return launch_split_t<7, 1, 1>(a, stream, grid_out);
     default:
       set_error("unsupported ONF feature dimension %d", a.geom.fin);
       return NFOPP_ERR_ARG;

@@ -232,9 +232,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
   };
 
   // Pipeline over this workgroup's chunks c0, c0 + grid, ...: while chunk k multiplies out of one LDS buffer, chunk k+1 is
-  // committed (registers -> LDS) and rebuilt in the other, and chunk k+2 is in flight from HBM.  Two barriers per chunk;
-  // between them a wave either rebuilds or multiplies, so the rebuild arithmetic of one wave overlaps the MFMAs of
-  // the others.
+  // committed (registers -> LDS) and rebuilt in the other, and chunk k+2 is in flight from HBM.  Two barriers per chunk,
+  // and between any two of them every wave has MFMAs of chunk k to issue, so one wave's commit / rebuild arithmetic
+  // overlaps the other waves' matrix work (the fp32 MFMA shares the vector ALU with its own wave's VALU work only).
   const long long c0 = blockIdx.x, step = gridDim.x;
   float* cur = lds;
   float* nxt = lds + W::BUF;
@@ -244,37 +244,48 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
     if (c0 + step < n_chunks) prefetch(c0 + step);
     __syncthreads();
     rebuild(cur);
+    __syncthreads();
   }
+  constexpr int GRP = 7;  // tiles whose operands are in flight together
+  // operands of step (tile group, k-step) it+1 are read from LDS while the MFMAs of step it issue
+  auto multiply = [&](int off, int j_lo, int j_hi) __attribute__((always_inline)) {
+#ifndef NFOPP_ABL_NO_MFMA
+    const int n_it = ((j_hi - j_lo + GRP - 1) / GRP) * (KC / 4);
+    float av[2][GRP], bv[2][GRP];
+    auto fetch = [&](int it, int buf) __attribute__((always_inline)) {
+      const int j0 = j_lo + GRP * (it / (KC / 4)), s = it % (KC / 4);
+#pragma unroll
+      for (int j = j0; j < j0 + GRP && j < W::TPW; ++j) {
+        av[buf][j - j0] = lds[off + pa[j] + 4 * s * W::STRIDE];
+        bv[buf][j - j0] = lds[off + pb[j] + 4 * s * W::STRIDE];
+      }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int it = 0; it < n_it; ++it) {
+      if (it + 1 < n_it) fetch(it + 1, (it + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int j0 = j_lo + GRP * (it / (KC / 4));
+#pragma unroll
+      for (int j = j0; j < j0 + GRP && j < W::TPW; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[it & 1][j - j0], bv[it & 1][j - j0], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+  };
+  constexpr int SPLIT_AT = GRP * ((W::TPW + GRP - 1) / GRP / 2 + ((W::TPW + GRP - 1) / GRP) % 2);   // groups before barrier A
   for (long long chunk = c0; chunk < n_chunks; chunk += step) {
     const bool has_next = chunk + step < n_chunks;
-    if (has_next) commit(nxt);                               // staged registers of chunk + step
+    const int off = (int)(cur - lds);
+    if (has_next) commit(nxt);                               // staged registers of chunk + step -> the free buffer
     if (chunk + 2 * step < n_chunks) prefetch(chunk + 2 * step);
-    __syncthreads();                                          // `cur` rebuilt by everyone, `nxt` committed by everyone
+    multiply(off, 0, SPLIT_AT);
+    __syncthreads();                                          // A: `nxt` committed by everyone
 #ifndef NFOPP_ABL_NO_REBUILD
     if (has_next) rebuild(nxt);
 #endif
-    const int off = (int)(cur - lds);
-#ifndef NFOPP_ABL_NO_MFMA
-    constexpr int GRP = 7;  // tiles whose operands are in flight together
-#pragma unroll
-    for (int j0 = 0; j0 < W::TPW; j0 += GRP) {
-#pragma unroll
-      for (int s = 0; s < KC / 4; ++s) {
-        float av[GRP], bv[GRP];
-#pragma unroll
-        for (int j = j0; j < j0 + GRP && j < W::TPW; ++j) {
-          av[j - j0] = lds[off + pa[j] + 4 * s * W::STRIDE];
-          bv[j - j0] = lds[off + pb[j] + 4 * s * W::STRIDE];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = j0; j < j0 + GRP && j < W::TPW; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j - j0], bv[j - j0], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#endif
-    __syncthreads();                                          // `cur` consumed, `nxt` rebuilt
+    multiply(off, SPLIT_AT, W::TPW);
+    __syncthreads();                                          // B: `cur` consumed, `nxt` rebuilt
     float* t = cur; cur = nxt; nxt = t;
   }
 #pragma unroll
@@ -299,11 +310,11 @@ __global__ __launch_bounds__(256) void onf_wgrad_reduce_kernel(const float* part
 
 struct GatherArgs {
   OnfGeom geom;
-  int nkt, aug_in_slot, n_loss_partials;
+  int nkt, aug_in_slot;
   const float* params;
   const float* reduced;       // [NTILES][256]
   const float* g4;            // [112] dW3[:100] in h2 slot order (reduced per-wave partials of pass 1)
-  const float* loss_partial;
+  const float* loss_partial;  // [1] summed loss
   float* grad;                // [n_params + 2]
   float count;
 };
@@ -359,10 +370,8 @@ __global__ __launch_bounds__(256) void onf_wgrad_gather_kernel(const GatherArgs 
     }
     a.grad[o] = v;
   }
-  if (o == 0) {  // mean BCE loss: per-wave partials in launch order
-    float s = 0.f;
-    for (int k = 0; k < a.n_loss_partials; ++k) s += a.loss_partial[k];
-    a.grad[g.n_params] = s;
+  if (o == 0) {  // mean BCE loss: the per-wave partials were summed by onf_rows_reduce_kernel (fixed tree)
+    a.grad[g.n_params] = a.loss_partial[0];
     a.grad[g.n_params + 1] = a.count;
   }
 }
@@ -375,7 +384,7 @@ static int find_aug_feature(int fin, int nkt) {
 }
 
 struct WgradWs {  // float offsets into the workspace
-  long long h1, dh1, de, rec, loss, g4_partial, g4, partial, reduced, total;
+  long long h1, dh1, de, rec, loss, loss_sum, g4_partial, g4, partial, reduced, total;
   int win, ntiles, grid_cap;
 };
 
@@ -391,6 +400,7 @@ static WgradWs carve_wgrad(const OnfGeom& g, long long P) {
   w.de = o; o += P * w.win;
   w.rec = o; o += P * 12;
   w.loss = o; o += (long long)w.grid_cap * 8;
+  w.loss_sum = o; o += 4;
   w.g4_partial = o; o += (long long)w.grid_cap * 8 * HS;
   w.g4 = o; o += HS;
   w.partial = o; o += (long long)w.grid_cap * w.ntiles * 256;
@@ -446,12 +456,13 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
   hipLaunchKernelGGL(onf_wgrad_reduce_kernel, dim3((n_elems + 255) / 256), dim3(256), 0, st, ws + w.partial,
                      ws + w.reduced, n_elems, grid);
   NFOPP_HIP(hipGetLastError());
-  // dW3[:100]: per-wave partials of pass 1, waves in launch order
+  // loss and dW3[:100]: per-wave partials of pass 1
+  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.loss, ws + w.loss_sum, 1, grid_fwd * 8);
+  NFOPP_HIP(hipGetLastError());
   hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(HS), dim3(256), 0, st, ws + w.g4_partial, ws + w.g4, HS, grid_fwd * 8);
   NFOPP_HIP(hipGetLastError());
   GatherArgs ga;
-  ga.geom = g; ga.nkt = nkt; ga.aug_in_slot = slot_layout_p(aug); ga.n_loss_partials = grid_fwd * 8;
-  ga.params = params; ga.reduced = ws + w.reduced; ga.g4 = ws + w.g4; ga.loss_partial = ws + w.loss; ga.grad = grad; ga.count = (float)P;
+  ga.geom = g; ga.nkt = nkt; ga.aug_in_slot = slot_layout_p(aug);   ga.params = params; ga.reduced = ws + w.reduced; ga.g4 = ws + w.g4; ga.loss_partial = ws + w.loss_sum; ga.grad = grad; ga.count = (float)P;
   hipLaunchKernelGGL(onf_wgrad_gather_kernel, dim3((g.n_params + 255) / 256), dim3(256), 0, st, ga);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;
