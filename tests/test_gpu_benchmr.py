@@ -259,3 +259,49 @@ def test_retired_trajectories_leave_the_onf_kernel():
     eng.active.copy_(torch.tensor(mask, device="cuda"))
     t_full, t_half = kernel_ms(ref), kernel_ms(eng)
     assert t_half < 0.65 * t_full, (t_half, t_full)     # 50 % live -> about half the time (+ LDS staging, compaction)
+
+
+def test_continuous_learning_full_size_and_two_shard_gradient():
+    """BASELINE configs[4] per GPU at its real size: 4096 trajectories x 512 waypoints, forward-only constraints,
+    continuous ONF learning on 4096 x 621 = 2 543 616 device-sampled poses per step (bench-mr hyper block, disc map).
+    There is one GPU under test, so the multi-rank step is checked by its arithmetic: the gradient each of two ranks
+    would contribute (its half of the trajectories, normalised by the GLOBAL sample count) must add up to the
+    single-rank gradient -- that sum is all the RCCL all-reduce does -- and the fit must be bitwise reproducible."""
+    z = load_golden("traj_benchmr_n512.npz")
+    onf, cfg = gc.make_onf(z["cfg"], z["params"])
+    hp = orc.Hyper.from_npz(z)
+    B, N = 4096, 512
+    bounds = (0.0, 100.0, 0.0, 100.0)
+    rng = np.random.default_rng(45)
+    starts = np.concatenate([rng.uniform(3, 97, (B, 2)), rng.uniform(-3, 3, (B, 1))], 1).astype(F32)
+    goals = np.concatenate([rng.uniform(3, 97, (B, 2)), rng.uniform(-3, 3, (B, 1))], 1).astype(F32)
+    checker = nfopp.DeviceCircleChecker(z["discs"], float(z["radius"]), bounds)
+    planner = nfopp.BatchPlanner(onf, B, N, gc.hyper_from(hp), checker=checker, fit_lr=2e-2, angle_offset=0.3, seed=11)
+    planner.init(starts, goals, bounds)
+    assert planner.sampler.S == N - 1 + 100 + 10
+    losses = []
+    for _ in range(3):
+        planner.step()
+        losses.append(float(planner.fitter.last_loss))
+    torch.cuda.synchronize()
+    assert np.isfinite(planner.get_paths()).all() and np.isfinite(losses).all()
+    assert planner.fitter.step_count == 3 and int(planner.fitter.grad[-1]) == B * planner.sampler.S
+    # the two-rank arithmetic on the samples of the last fit
+    samples = planner.sampler.samples.view(-1, 3)
+    labels = planner.sampler.labels
+    total = samples.shape[0]
+    half = (B // 2) * planner.sampler.S
+    fit = nfopp.OnfFitter(onf, 2e-2, (0.9, 0.9), distributed=False)
+    fit._hip_grad(samples, labels, 1.0 / total)
+    g_full = fit.grad.clone()
+    fit._hip_grad(samples, labels, 1.0 / total)
+    assert torch.equal(fit.grad, g_full)                                  # bitwise reproducible at full size
+    fit._hip_grad(samples[:half].contiguous(), labels[:half].contiguous(), 1.0 / total)
+    g_a = fit.grad.clone()
+    fit._hip_grad(samples[half:].contiguous(), labels[half:].contiguous(), 1.0 / total)
+    g_sum = (g_a + fit.grad).cpu().numpy()
+    g_full = g_full.cpu().numpy()
+    assert g_sum[-1] == total
+    scale = float(np.abs(g_full[:-2]).max())
+    assert max_abs(g_sum[:-2], g_full[:-2]) < 2e-5 * scale                # summation order only
+    assert abs(g_sum[-2] - g_full[-2]) < 1e-5 * abs(g_full[-2])           # global mean loss
