@@ -85,14 +85,14 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_fwd_bwd_kernel(con
     const float* w1a = W1 + rowposQ * S1 + colP;
     const float* w1b = w1a + 64 * S1;
     const float* w1c = W1 + (96 + gi) * S1 + colP;
-    const float* ftl = lds + L::FT + L::FTS * colP;
+    const float* ftl = lds + L::ft(colP);   // lane part of every feature-table address (+ L::ft_rel(block or tile base))
     const float* isl = lds + L::ISA + colP;
 
     auto l1_tile = [&](auto ang_c, int kt) __attribute__((always_inline)) {
       constexpr bool ANG = decltype(ang_c)::value;
       constexpr bool ang_tile = ANG;
       const int off = base_p(kt);
-      const float* fte = ftl + L::FTS * off;
+      const float* fte = ftl + L::ft_rel(off);
       const float* pa = w1a + off;
       const float* pb = w1b + off;
       const float* pc = w1c + off;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_fwd_bwd_kernel(con
       }
       // chain through the encodings: d feature / d arg = sin(arg + (qh + 0.5) pi); rows (g, r) <-> slots (4 mt + r, g)
       constexpr bool ang_tile = ANG;
-      const float* fte = lds + L::FT + L::FTS * fbase;
+      const float* fte = lds + L::ft(fbase);
       if (NT == 2) {
         const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
         f32x2 gx2 = {gx[0], gx[NT - 1]}, gy2 = {gy[0], gy[NT - 1]}, gt2 = {gt[0], gt[NT - 1]};

@@ -29,7 +29,22 @@ struct Lds {
   static constexpr int W2 = W1 + H * S1;
   static constexpr int FT = ((W2 + H * S2 + 3) / 4) * 4;  // feature table, FTS floats per input feature
   static constexpr int FTS = 12;                          // (wx wx wy wy | b b fr fr | qh qh w3b w3b): packed-math pairs
-  static constexpr int B1 = FT + NF * FTS;                // 112 each, D-layout indexable (see fill)
+  // The table is read with 16-byte accesses by lanes whose feature indices differ by 16 (lane group bit g & 1) and by 4
+  // (g >> 1).  ds_read_b128 serves lanes of BOTH values of g & 1 in one cycle group, and 16 entries = 192 floats = 0 mod
+  // 64 banks: a plain [feature][FTS] table is 2-way conflicted on every read (22 % of the kernel's LDS cycles in round
+  // 1's counters).  So the table is stored in two halves by bit 4 of the feature index, the second half 32 banks further.
+  static constexpr int FT_HALF = ((NF / 2) * FTS / 64) * 64 + 64 + 32;   // float offset of the second half, = 32 mod 64
+  static constexpr int FT_FLOATS = FT_HALF + (NF / 2) * FTS;
+  // entry of feature f, floats from the start of LDS;  ft_rel(x): the part that does not depend on the lane, for
+  // x = 32 K + c with c < 16 (block / tile bases and row offsets: bit 4 clear)
+#ifndef NFOPP_FT_PLAIN
+  __host__ __device__ static constexpr int ft(int f) { return FT + FT_HALF * ((f >> 4) & 1) + FTS * (((f >> 5) << 4) | (f & 15)); }
+  __host__ __device__ static constexpr int ft_rel(int x) { return FTS * (x - 16 * (x >> 5)); }
+#else   /* development A/B: the plain [feature][FTS] table of round 1 (2-way conflicted 16-byte reads) */
+  __host__ __device__ static constexpr int ft(int f) { return FT + FTS * f; }
+  __host__ __device__ static constexpr int ft_rel(int x) { return FTS * x; }
+#endif
+  static constexpr int B1 = FT + ((FT_FLOATS + 3) / 4) * 4;   // 112 each, D-layout indexable (see fill)
   static constexpr int B2 = B1 + 16 * HT;
   static constexpr int W3A = B2 + 16 * HT;
   static constexpr int W3B = W3A + 16 * HT;               // NF skip weights
@@ -110,7 +125,7 @@ __device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
     } else if (TRAIN && f == a.aug_feature) {
       qh = NFOPP_Q_UNIT;  // all weights zero: sin(0 + pi/2) = 1
     }
-    float* e = lds + L::FT + L::FTS * f;
+    float* e = lds + L::ft(f);
     e[0] = e[1] = wx; e[2] = e[3] = wy; e[4] = e[5] = b; e[6] = e[7] = fr;
     e[8] = e[9] = qh; e[10] = e[11] = w3b;
     lds[L::W3B + f] = w3b;

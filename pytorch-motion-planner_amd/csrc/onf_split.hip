@@ -204,6 +204,11 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds<NKT, TRAIN, true>(lds, a);
   __syncthreads();
+#ifndef NFOPP_NO_PRIO_YOUNG
+  // the second-dispatched half of the workgroup loses the vector-issue arbitration (age); one static priority for that
+  // half, set once, evens it out (MI355X_MICROARCH.md "static priority for the younger half"; -0.4 % in a same-process A/B)
+  if ((threadIdx.x >> 6) >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
   const OnfGeom& geo = a.geom;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
     const float* w1a = W1 + rowposQ * S1 + colP;
     const float* w1b = w1a + 64 * S1;
     const float* w1c = W1 + (96 + gi) * S1 + colP;
-    const float* ftl = lds + L::FT + L::FTS * colP;
+    const float* ftl = lds + L::ft(colP);   // lane part of every feature-table address (+ L::ft_rel(block or tile base))
     const float* isl = lds + L::ISA + colP;
 
     u32x4 q0 = lo_frag(B::L1), q1 = lo_frag(B::L1 + 1);   // third-level fragments of the next two steps
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
         float fv[NT][8];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          const float* fte = ftl + L::FTS * (off + 8 * half);
+          const float* fte = ftl + L::ft_rel(off + 8 * half);
           if (NT == 2) {
             const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
             f32x2 sk = {skip[0], skip[NT - 1]};
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       float tb[2];          // its bias
       int nxt_off = 0;      // 32 (kb + 1): feature offset of the block being prepared
       auto table_load = [&](int j) __attribute__((always_inline)) {
-        const float* e = ftl + L::FTS * (nxt_off + 8 * (j >> 2) + (j & 3));
+        const float* e = ftl + L::ft_rel(nxt_off + 8 * (j >> 2) + (j & 3));
         tw[j & 1] = *reinterpret_cast<const f32x4*>(e);
         tb[j & 1] = e[4];
         tq[j & 1] = *reinterpret_cast<const f32x4*>(e + 8);
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
         float fv[NT][8];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          const float* fte = ftl + L::FTS * (off + 8 * half);
+          const float* fte = ftl + L::ft_rel(off + 8 * half);
           const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
           f32x2 sk = {skip[0], skip[NT - 1]};
           f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
         for (int j = 0; j < 8; ++j) wat[j] = wbt[j];
         __builtin_amdgcn_sched_barrier(0);
       }
-      const float* fte = lds + L::FT + L::FTS * fbase;
+      const float* fte = lds + L::ft(fbase);
       if (NT == 2) {
         const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
         f32x2 gx2 = {gx[0], gx[NT - 1]}, gy2 = {gy[0], gy[NT - 1]}, gt2 = {gt[0], gt[NT - 1]};
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       float db[2], dq[2];   // bias, quadrant offset + a quarter turn (derivative)
       int pm_base = 0;      // base_p(mt - 1) + colP: first feature of the tile whose epilogue is in flight
       auto dtable_load = [&](int r) __attribute__((always_inline)) {
-        const float* e = lds + L::FT + L::FTS * (pm_base + r);
+        const float* e = lds + L::ft(pm_base + r);
         dw[r & 1] = *reinterpret_cast<const f32x4*>(e);
         db[r & 1] = e[4];
         dq[r & 1] = e[8] + NFOPP_Q_UNIT;
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       auto epilogue = [&](auto ang_c, int mt, const f32x4 (&acc)[NT]) __attribute__((always_inline)) {   // as l1t_tile
         constexpr bool ANG = decltype(ang_c)::value;
         const int fbase = base_p(mt) + colP;
-        const float* fte = lds + L::FT + L::FTS * fbase;
+        const float* fte = lds + L::ft(fbase);
         const f32x2 ux2 = {ux[0], ux[NT - 1]}, uy2 = {uy[0], uy[NT - 1]}, th2 = {th[0], th[NT - 1]};
         f32x2 gx2 = {gx[0], gx[NT - 1]}, gy2 = {gy[0], gy[NT - 1]}, gt2 = {gt[0], gt[NT - 1]};
         f32x4 isa4 = {0.f, 0.f, 0.f, 0.f};

@@ -1,0 +1,55 @@
+"""Dev tool: A/B two builds of libnfopp_hip.so IN ONE PROCESS, interleaved rounds (guide rule 24): the fused ONF kernel on
+the cfg3 shape.  Usage: python tools/ab_libs.py build/<variant>/libnfopp_hip.so   (compared with the product build)"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-motion-planner_amd"))
+import nfopp  # noqa: E402
+from nfopp import _lib  # noqa: E402
+
+
+def bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _lib._SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+libs = {"product": bind(_lib.LIB_PATH), "variant": bind(os.path.abspath(sys.argv[1]))}
+torch.manual_seed(0)
+onf = nfopp.ONF(0.0, 10.0, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to("cuda")
+B, N = 4096, 256
+traj = torch.rand(B, N, 3, device="cuda") * torch.tensor([100.0, 100.0, 6.0], device="cuda")
+t = torch.zeros(B, N - 1, device="cuda")
+out = {k: torch.zeros(B, N - 1, 4, device="cuda") for k in libs}
+cfg = onf.config_c()
+
+
+def run(lib, o):
+    rc = lib.nfopp_traj_collision_eval(cfg, _lib.ptr(onf.flat_parameters), _lib.ptr(traj), B, N, 3, _lib.ptr(t), 1, 7, 0, 0,
+                                       _lib.ptr(o), None, None, _lib.stream_ptr())
+    assert rc == 0, lib.nfopp_last_error()
+
+
+times = {k: [] for k in libs}
+for rnd in range(8):
+    for k, lib in libs.items():
+        for _ in range(3):
+            run(lib, out[k])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            run(lib, out[k])
+        b.record()
+        torch.cuda.synchronize()
+        times[k].append(a.elapsed_time(b) / 20)
+for k, v in times.items():
+    print("%-8s median %.4f ms  min %.4f  (rounds: %s)" % (k, float(np.median(v)), min(v), " ".join("%.3f" % x for x in v)))
+print("variant / product (median): %.4f" % (np.median(times["variant"]) / np.median(times["product"])))
+print("outputs identical:", bool(torch.equal(out["product"], out["variant"])))
