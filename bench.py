@@ -390,7 +390,7 @@ def main():
                        "paths_finite": finite, "matrix_path": matrix_path, "planner_steps_per_s": args.steps / elapsed},
             "roofline": roofline(matrix_path, achieved, k1_ms, samples, traffic, traffic_source),
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # the CPU legs run at N = 1 only (bench contract); N > 1 lines carry the rate
             sample = min(args.cpu_sample, hi - lo)
             flat = onf.flat_parameters.cpu().numpy()
             cpu = cpu_baselines(flat, starts, goals, N, sample, args.cpu_seconds)
