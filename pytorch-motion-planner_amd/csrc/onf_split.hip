@@ -831,9 +831,11 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
           const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, isa, ux2, uy2, th2);
           const f32x2 de = f32x2{acc[0][r], acc[0][r + 1]} * cof;
           if (TRAIN) { acc[0][r] = de.x; acc[0][r + 1] = de.y; }
-          gx[0] = fmaf(de.x, wx.x, gx[0]); gx[0] = fmaf(de.y, wx.y, gx[0]);
-          gy[0] = fmaf(de.x, wy.x, gy[0]); gy[0] = fmaf(de.y, wy.y, gy[0]);
-          if (ANG) { gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]); }
+          if (!TRAIN) {   // the fit needs de only, not d logit / d pose
+            gx[0] = fmaf(de.x, wx.x, gx[0]); gx[0] = fmaf(de.y, wx.y, gx[0]);
+            gy[0] = fmaf(de.x, wy.x, gy[0]); gy[0] = fmaf(de.y, wy.y, gy[0]);
+            if (ANG) { gt[0] = fmaf(de.x, fr.x, gt[0]); gt[0] = fmaf(de.y, fr.y, gt[0]); }
+          }
         }
       }
       if (TRAIN) {

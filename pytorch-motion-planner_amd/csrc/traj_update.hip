@@ -13,6 +13,9 @@
 namespace nfopp {
 
 constexpr int TU_THREADS = 256;
+#ifndef NFOPP_K2_WAVES
+#define NFOPP_K2_WAVES 1   /* minimum waves per SIMD the register allocation aims at (A/B: 6 and 8 below) */
+#endif
 
 struct TrajUpdateArgs {
   nfopp_traj_hyper hp;
@@ -114,19 +117,36 @@ __device__ __forceinline__ void collision_terms(const nfopp_traj_hyper& hp, floa
 }
 
 template <int D>
-__global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdateArgs a) {
+__global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel(const TrajUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = a.n;
+  const int W = a.half_width, NB_LO = a.interior_lo, NB = a.interior_lo + (N - a.interior_hi);  // boundary columns
   float* Q = sm;                    // (N+2) * D full trajectory
-  float* G = Q + (N + 2) * D;       // N * D gradient
-  float* LAM = G + N * D;           // N+1 constraint multipliers (read-only copy: the update writes global)
+  float* GP = Q + (N + 2) * D;      // (N + 2W) * D gradient, W zero rows on either side: every tap of every waypoint is
+  float* G = GP + W * D;            //   in range, so the band loop is uniform over the workgroup
+  float* LAM = GP + (N + 2 * W) * D;  // N+1 constraint multipliers (read-only copy: the update writes global)
   float* CM = LAM + (N + 1);        // N collision multipliers
-  float* COEF = CM + N;             // 2W+1 interior band coefficients
-  float* scratch = COEF + (2 * a.half_width + 1);  // block reductions
-  const long long b = blockIdx.x;
-  if (a.active && !a.active[b]) return;  // retired trajectory (uniform per workgroup)
+  float* COEF = CM + N;             // 2W+1 interior band coefficients (Toeplitz interior: one column for all)
+  float* BND = COEF + (2 * W + 1);  // NB * (2W+1): the band columns of the waypoints near the two ends
+  float* scratch = BND + NB * (2 * W + 1);  // block reductions
   const nfopp_traj_hyper& hp = a.hp;
   const int tid = threadIdx.x;
+
+  // once per workgroup: preconditioner coefficients (the boundary waves used to fetch their 2W+1 coefficients from global
+  // memory inside the band loop, 4 in flight: 27 % of the kernel) and the zero rows around the gradient
+  if (a.interior_hi > a.interior_lo)
+    for (int k = tid; k <= 2 * W; k += TU_THREADS) COEF[k] = a.hinv_band[(long long)k * N + a.interior_lo];
+  for (int idx = tid; idx < NB * (2 * W + 1); idx += TU_THREADS) {
+    const int k = idx / NB, c = idx - k * NB;                 // consecutive threads: consecutive columns of one band row
+    const int w = c < NB_LO ? c : a.interior_hi + (c - NB_LO);
+    BND[c * (2 * W + 1) + k] = a.hinv_band[(long long)k * N + w];
+  }
+  for (int k = tid; k < W * D; k += TU_THREADS) { GP[k] = 0.0f; GP[(N + W) * D + k] = 0.0f; }
+
+  // one trajectory per workgroup (walking several in a row measured slower: nothing overlaps between a workgroup's
+  // trajectories, and the loop costs 36 VGPRs = one wave per SIMD)
+  const long long b = blockIdx.x;
+  if (a.active && !a.active[b]) return;  // retired trajectory (uniform per workgroup)
 
   float* traj = a.traj + b * N * D;
   for (int k = tid; k < N * D; k += TU_THREADS) Q[D + k] = traj[k];
@@ -138,10 +158,9 @@ __global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdat
     for (int k = tid; k <= N; k += TU_THREADS) LAM[k] = a.lam[b * (N + 1) + k];
     for (int k = tid; k < N; k += TU_THREADS) CM[k] = a.cm[b * N + k];
   }
-  if (a.interior_hi > a.interior_lo)
-    for (int k = tid; k <= 2 * a.half_width; k += TU_THREADS) COEF[k] = a.hinv_band[(long long)k * N + a.interior_lo];
   __syncthreads();
 
+  // (staging t / the ONF records in LDS with the state loads measured slower, twice: round 1 and round 2)
   const float* tb = a.t + b * (N - 1);
   const float* onf = a.onf + b * (N - 1) * 4;
   float terms[NFOPP_NUM_TERMS];
@@ -237,46 +256,27 @@ __global__ __launch_bounds__(TU_THREADS) void traj_update_kernel(const TrajUpdat
   }
   __syncthreads();
 
-  // g <- H^-1 g with the band of the reference's fp32 inverse (nerf:151), then Adam (torch single-tensor path)
-  const int W = a.half_width;
+  // g <- H^-1 g with the band of the reference's fp32 inverse (nerf:151), then Adam (torch single-tensor path).
+  // Taps k = 0 .. 2W in ascending order for every waypoint; out-of-range taps meet a zero band entry and a zero-padded
+  // gradient row, so the sum is the same fp32 chain as over the valid taps alone.
   float* am = a.adam_m + b * N * D;
   float* av = a.adam_v + b * N * D;
   for (int w = tid; w < N; w += TU_THREADS) {
     float acc[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
-    const int k0 = max(0, W - w), k1 = min(2 * W, N - 1 - w + W);
-    const float* hb = a.hinv_band + w;
-    const float* gj = G + (w - W) * D;
-    // optimiser state is independent of the band product: issue its loads before the (latency-bound) taps
+    // optimiser state is independent of the band product: issue its loads before the taps
     float m_in[D], v_in[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { m_in[d] = am[w * D + d]; v_in[d] = av[w * D + d]; }
-    if (__all(w >= a.interior_lo && w < a.interior_hi)) {
-      // interior wave: every lane's band column is the SAME vector -> coefficients broadcast from LDS, no global loads
-      for (int k = 0; k <= 2 * W; ++k) {
-        const float hv = COEF[k];
+    const bool interior = w >= a.interior_lo && w < a.interior_hi;
+    const float* cf = interior ? COEF : BND + (w < a.interior_lo ? w : NB_LO + (w - a.interior_hi)) * (2 * W + 1);
+    const float* gj = GP + w * D;   // row w - W of the unpadded gradient
+#pragma unroll 4
+    for (int k = 0; k <= 2 * W; ++k) {
+      const float hv = cf[k];
 #pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
-      }
-    } else {
-      int k = k0;
-      if (__all(k0 == 0 && k1 == 2 * W)) {   // full band for the whole wave: 4 taps in flight per trip
-        for (; k + 3 <= k1; k += 4) {
-          float hv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) hv[u] = hb[(long long)(k + u) * N];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] = fmaf(hv[u], gj[(k + u) * D + d], acc[d]);
-        }
-      }
-      for (; k <= k1; ++k) {
-        const float hv = hb[(long long)k * N];
-#pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
-      }
+      for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -333,15 +333,17 @@ extern "C" int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int3
   a.adam_m = adam_m_dev; a.adam_v = adam_v_dev; a.t = t_dev; a.onf = onf_out4_dev;
   a.hinv_band = hinv_band_dev; a.half_width = half_width; a.terms = terms_dev; a.active = active_dev;
   a.interior_lo = interior_lo; a.interior_hi = interior_hi > interior_lo ? interior_hi : interior_lo;
-  const size_t lds = (size_t)((n_waypoints + 2) * dim + n_waypoints * dim + 2 * n_waypoints + 1 +
-                              2 * half_width + 1 + NFOPP_NUM_TERMS * (TU_THREADS / 64)) * 4;
+  const int n_boundary = a.interior_lo + (n_waypoints - a.interior_hi);
+  const size_t lds = (size_t)((n_waypoints + 2) * dim + (n_waypoints + 2 * half_width) * dim + 2 * n_waypoints + 1 +
+                              (n_boundary + 1) * (2 * half_width + 1) + NFOPP_NUM_TERMS * (TU_THREADS / 64)) * 4;
   NFOPP_REQUIRE(lds <= 160 * 1024, "trajectory too long for one workgroup's LDS (%zu bytes)", lds);
   NFOPP_REQUIRE(batch <= 0x7fffffffLL, "batch too large for one launch");
   auto kern = dim == 3 ? traj_update_kernel<3> : traj_update_kernel<2>;
   if (lds > 64 * 1024)
     NFOPP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(TU_THREADS), lds, (hipStream_t)stream, a);
+  const long long grid = batch;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TU_THREADS), lds, (hipStream_t)stream, a);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;
 }

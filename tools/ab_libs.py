@@ -22,6 +22,7 @@ def bind(path):
 
 
 libs = {"product": bind(_lib.LIB_PATH), "variant": bind(os.path.abspath(sys.argv[1]))}
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "k1"     # k1: fused ONF kernel, k2: stencil / optimiser kernel
 torch.manual_seed(0)
 onf = nfopp.ONF(0.0, 10.0, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to("cuda")
 B, N = 4096, 256
@@ -36,6 +37,28 @@ def run(lib, o):
                                        _lib.ptr(o), None, None, _lib.stream_ptr())
     assert rc == 0, lib.nfopp_last_error()
 
+
+if KERNEL == "k2":
+    from nfopp.engine import TrajectoryEngine, TrajectoryHyper
+    hyper = TrajectoryHyper(100, 5, 100, 0.1, 1e-3, 1, 10, 100, 5e-2, (0.9, 0.9), 1e-8, (0, 100, 0, 100))
+    engs = {}
+    for k in libs:
+        e = TrajectoryEngine(onf, B, N, 3, hyper, 0.5, "cuda")
+        e.traj.copy_(traj)
+        e.set_endpoints(traj[:, 0].cpu().numpy(), traj[:, -1].cpu().numpy())
+        run(libs[k], e.onf_out)
+        e.t.copy_(t)
+        engs[k] = e
+
+    def run(lib, o, _libs=libs, _engs=engs):   # noqa: F811
+        e = _engs["product" if lib is _libs["product"] else "variant"]
+        e.adam_step += 1
+        hp = e.hyper.to_c(e.adam_step)
+        rc = lib.nfopp_traj_update(hp, e.B, e.N, e.D, _lib.ptr(e.traj), _lib.ptr(e.start), _lib.ptr(e.goal), _lib.ptr(e.lam),
+                                   _lib.ptr(e.cm), _lib.ptr(e.adam_m), _lib.ptr(e.adam_v), _lib.ptr(e.t), _lib.ptr(e.onf_out),
+                                   _lib.ptr(e.hinv_band), e.half_width, e.interior[0], e.interior[1], None, None, _lib.stream_ptr())
+        assert rc == 0, lib.nfopp_last_error()
+    out = {k: engs[k].traj for k in libs}
 
 times = {k: [] for k in libs}
 for rnd in range(8):
