@@ -1,11 +1,14 @@
-"""Planner construction with the reference's factory entry points.
+"""Planner construction behind the reference's two factory entry points.
 
-`PlannerFactory.make_onf_planner / make_constrained_onf_planner` and `UniversalFactory` follow
-nfop/planner_factory.py:11-77 and nfop/utils/universal_factory.py:9-44: classes are resolved by `name`, keyword
-arguments the constructor does not accept are silently dropped, an unknown name raises KeyError.  The only
-difference a caller sees is `device`: this path is HIP-only, so the default device is "cuda" and "cpu" is rejected.
+What a driver of the reference relies on (nfop/planner_factory.py:11-77, nfop/utils/universal_factory.py:9-44) and what is
+kept here: `PlannerFactory.make_onf_planner(checker)` and `PlannerFactory.make_constrained_onf_planner(checker, parameters)`
+return a ready planner; nested parameter dictionaries whose `name` (or `type`) names a registered class are turned into
+objects, keyword arguments that class does not take are dropped without complaint, an unregistered name raises
+`KeyError("Unknown class ...")`; the default parameter block has the reference's values (and, like the reference's, no
+`trajectory_initializer` entry).  The one visible difference is `device`: this path is HIP-only, so the default is "cuda"
+and "cpu" is refused.
 """
-from inspect import signature
+import inspect
 
 import torch
 
@@ -13,82 +16,104 @@ from .host_utils import AstarTrajectoryInitializer, AttributeDict, TrajectoryIni
 from .onf_model import ONF
 from .planner import ConstrainedNERFOptPlanner, NERFOptPlanner
 
-PARAMETER_ATTRIBUTE_NAMES = ("parameters", "params", "param", "parameter")
-CLASS_NAME_ATTRIBUTES = ("name", "type")
 
-DEFAULT_PARAMETERS = AttributeDict(
-    device="cuda",
-    trajectory_length=100,
-    collision_model=AttributeDict(mean=0, sigma=10, use_cos=True, bias=True, use_normal_init=True, name="ONF"),
-    collision_optimizer=AttributeDict(lr=1e-2, betas=(0.9, 0.9)),
-    trajectory_optimizer=AttributeDict(lr=1e-2, betas=(0.9, 0.9)),
-    planner=AttributeDict(name="ConstrainedNERFOptPlanner", trajectory_random_offset=0.02, collision_weight=1,
-                          velocity_hessian_weight=0.5, random_field_points=10, init_collision_iteration=0,
-                          constraint_deltas_weight=0.2, multipliers_lr=0.001, init_collision_points=100,
-                          reparametrize_trajectory_freq=10, optimize_collision_model_freq=1, angle_weight=0.5,
-                          boundary_weight=1, collision_multipliers_lr=1e-3),
-)
+def _as_attribute_dicts(tree):
+    """Plain nested dicts -> AttributeDicts (attribute access, as the reference's drivers index their parameters)."""
+    if isinstance(tree, dict):
+        return AttributeDict({key: _as_attribute_dicts(value) for key, value in tree.items()})
+    return tree
+
+
+# values of the reference's default block (nfop/planner_factory.py:11-46), device aside
+_ADAM_DEFAULT = {"lr": 1e-2, "betas": (0.9, 0.9)}
+DEFAULT_PARAMETERS = _as_attribute_dicts({
+    "device": "cuda",
+    "trajectory_length": 100,
+    "collision_model": {"name": "ONF", "mean": 0, "sigma": 10, "use_cos": True, "bias": True, "use_normal_init": True},
+    "collision_optimizer": dict(_ADAM_DEFAULT),
+    "trajectory_optimizer": dict(_ADAM_DEFAULT),
+    "planner": {
+        "name": "ConstrainedNERFOptPlanner",
+        "collision_weight": 1, "velocity_hessian_weight": 0.5, "angle_weight": 0.5, "boundary_weight": 1,
+        "constraint_deltas_weight": 0.2, "multipliers_lr": 0.001, "collision_multipliers_lr": 1e-3,
+        "trajectory_random_offset": 0.02, "random_field_points": 10,
+        "init_collision_iteration": 0, "init_collision_points": 100,
+        "reparametrize_trajectory_freq": 10, "optimize_collision_model_freq": 1,
+    },
+})
+
+# the fixed recipe of the 2-D planner (nfop/planner_factory.py:50-59)
+_ONF_2D = {"mean": 1.5, "sigma": 1, "field_lr": 1e-3, "field_betas": (0.9, 0.9), "waypoints": 100,
+           "trajectory_lr": 1e-2, "trajectory_betas": (0.9, 0.999),
+           "planner": {"trajectory_random_offset": 0.02, "collision_weight": 0.01, "velocity_hessian_weight": 3,
+                       "random_field_points": 10, "init_collision_iteration": 400}}
 
 
 class UniversalFactory(object):
+    """Builds objects from parameter dictionaries: `{"name": <registered class>, <constructor arguments>...}`."""
+
+    NAME_KEYS = ("name", "type")
+    WHOLE_DICT_ARGUMENTS = ("parameters", "params", "param", "parameter")   # constructors that want the dict itself
+
     def __init__(self, classes):
-        self._classes = {c.__name__: c for c in classes}
+        self._registry = dict((cls.__name__, cls) for cls in classes)
+
+    def _lookup(self, parameters):
+        found = None
+        for key in self.NAME_KEYS:
+            if key in parameters:
+                class_name = parameters[key]
+                if class_name not in self._registry:
+                    raise KeyError("Unknown class %s" % class_name)
+                found = self._registry[class_name]
+        return found
 
     def make_from_parameters(self, parameters, **kwargs):
         if not isinstance(parameters, dict):
-            return parameters
-        ctor = None
-        for attribute in CLASS_NAME_ATTRIBUTES:
-            if attribute in parameters:
-                try:
-                    ctor = self._classes[parameters[attribute]]
-                except KeyError:
-                    raise KeyError("Unknown class %s" % parameters[attribute])
-        if ctor is None:
-            return parameters
-        for key, value in parameters.items():
-            kwargs[key] = self.make_from_parameters(value)
-        accepted = signature(ctor).parameters.keys()
-        for name in PARAMETER_ATTRIBUTE_NAMES:
-            if name in accepted:
-                kwargs[name] = parameters
-        return ctor(**{k: v for k, v in kwargs.items() if k in accepted})
+            return parameters                      # leaves: numbers, tuples, ready-made objects
+        cls = self._lookup(parameters)
+        if cls is None:
+            return parameters                      # a dictionary that names no class stays a dictionary
+        arguments = dict(kwargs)
+        arguments.update((key, self.make_from_parameters(value)) for key, value in parameters.items())
+        takes = inspect.signature(cls).parameters
+        arguments.update((key, parameters) for key in self.WHOLE_DICT_ARGUMENTS if key in takes)
+        return cls(**dict((key, value) for key, value in arguments.items() if key in takes))
 
 
-def _device(parameters):
-    device = torch.device(parameters.get("device", "cuda"))
+def _hip_device(requested):
+    device = torch.device(requested)
     if device.type != "cuda":
         raise RuntimeError("nfopp runs the planner step on MI355X only: set parameters.device='cuda' (got %r); "
-                           "there is no CPU fallback" % (parameters.get("device"),))
+                           "there is no CPU fallback" % (requested,))
     return device
+
+
+def _adam(tensors, lr, betas):
+    return torch.optim.Adam(tensors, lr, betas=betas)
 
 
 class PlannerFactory(object):
     @staticmethod
     def make_onf_planner(collision_checker, device="cuda"):
-        device = _device({"device": device})
-        collision_model = ONF(1.5, 1).to(device)
-        collision_optimizer = torch.optim.Adam(collision_model.parameters(), 1e-3, betas=(0.9, 0.9))
-        trajectory = torch.zeros(100, 2, requires_grad=True, device=device)
-        trajectory_optimizer = torch.optim.Adam([trajectory], 1e-2, betas=(0.9, 0.999))
-        return NERFOptPlanner(trajectory, collision_model, collision_checker, collision_optimizer, trajectory_optimizer,
-                              trajectory_random_offset=0.02, collision_weight=0.01, velocity_hessian_weight=3,
-                              random_field_points=10, init_collision_iteration=400)
+        recipe, device = _ONF_2D, _hip_device(device)
+        field = ONF(recipe["mean"], recipe["sigma"]).to(device)
+        waypoints = torch.zeros(recipe["waypoints"], 2, requires_grad=True, device=device)
+        return NERFOptPlanner(waypoints, field, collision_checker,
+                              _adam(field.parameters(), recipe["field_lr"], recipe["field_betas"]),
+                              _adam([waypoints], recipe["trajectory_lr"], recipe["trajectory_betas"]), **recipe["planner"])
 
     @staticmethod
     def make_constrained_onf_planner(collision_checker, parameters=None):
-        if parameters is None:
-            parameters = DEFAULT_PARAMETERS
-        factory = UniversalFactory([ONF, ConstrainedNERFOptPlanner, TrajectoryInitializer, AstarTrajectoryInitializer])
-        device = _device(parameters)
-        collision_model = factory.make_from_parameters(parameters.collision_model).to(device)
-        collision_optimizer = torch.optim.Adam(collision_model.parameters(), **parameters.collision_optimizer)
-        trajectory = torch.zeros(parameters.trajectory_length, 3, requires_grad=True, device=device)
-        trajectory_optimizer = torch.optim.Adam([trajectory], **parameters.trajectory_optimizer)
-        trajectory_initializer = factory.make_from_parameters(parameters.trajectory_initializer,
-                                                              collision_checker=collision_checker)
-        return factory.make_from_parameters(parameters.planner, trajectory=trajectory, collision_model=collision_model,
-                                            collision_checker=collision_checker,
-                                            collision_optimizer=collision_optimizer,
-                                            trajectory_optimizer=trajectory_optimizer,
-                                            trajectory_initializer=trajectory_initializer)
+        p = DEFAULT_PARAMETERS if parameters is None else parameters
+        device = _hip_device(p.get("device", "cuda"))
+        build = UniversalFactory([ONF, ConstrainedNERFOptPlanner, TrajectoryInitializer,
+                                  AstarTrajectoryInitializer]).make_from_parameters
+        parts = {"collision_checker": collision_checker}
+        parts["collision_model"] = build(p.collision_model).to(device)
+        parts["trajectory"] = torch.zeros(p.trajectory_length, 3, requires_grad=True, device=device)
+        parts["collision_optimizer"] = torch.optim.Adam(parts["collision_model"].parameters(), **p.collision_optimizer)
+        parts["trajectory_optimizer"] = torch.optim.Adam([parts["trajectory"]], **p.trajectory_optimizer)
+        # DEFAULT_PARAMETERS has no initialiser entry: AttributeError here, exactly as with the reference's defaults
+        parts["trajectory_initializer"] = build(p.trajectory_initializer, collision_checker=collision_checker)
+        return build(p.planner, **parts)
