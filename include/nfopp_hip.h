@@ -157,6 +157,14 @@ int nfopp_onf_train_grad_ex(const nfopp_onf_config* cfg, const float* params_dev
 int nfopp_check_collision_circle(const float* poses_dev, int64_t n, int32_t pose_dim, const float* obstacles_dev,
                                  int32_t n_obstacles, float radius, const float* bounds4, float* labels_dev,
                                  void* stream);
+/* The circle checker with a uniform cell index over the obstacle points (same labels, far fewer distance tests):
+ * obstacles_sorted_dev [n_obstacles, 2] sorted by cell (row-major cells of cell_size >= radius, origin cell_x0 / cell_y0),
+ * cell_start_dev [cells_x * cells_y + 1] = first point of each cell. */
+int nfopp_check_collision_circle_cells(const float* poses_dev, int64_t n, int32_t pose_dim,
+                                       const float* obstacles_sorted_dev, int32_t n_obstacles,
+                                       const int32_t* cell_start_dev, int32_t cells_x, int32_t cells_y, float cell_x0,
+                                       float cell_y0, float cell_size, float radius, const float* bounds4,
+                                       float* labels_dev, void* stream);
 int nfopp_check_collision_rectangle(const float* poses_dev, int64_t n, const float* obstacles_dev, int32_t n_obstacles,
                                     const float* box4, const float* bounds4, float* labels_dev, void* stream);
 int nfopp_check_collision_grid(const float* poses_dev, int64_t n, int32_t pose_dim, const uint8_t* grid_dev,

@@ -66,6 +66,9 @@ _SIGNATURES = {
                                                _P, _P, ctypes.c_size_t, ctypes.c_int32, _P]),
     "nfopp_check_collision_circle": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_float,
                                                     ctypes.POINTER(ctypes.c_float), _P, _P]),
+    "nfopp_check_collision_circle_cells": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int32, _P,
+                                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                                          ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float), _P, _P]),
     "nfopp_check_collision_rectangle": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int32,
                                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _P, _P]),
     "nfopp_check_collision_grid": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,

@@ -21,19 +21,45 @@ def _f4(values):
 
 
 class DeviceCircleChecker(object):
-    """Disc robot against a point cloud + bounds (nfop/collision_checker/circle_collision_checker.py)."""
+    """Disc robot against a point cloud + bounds (nfop/collision_checker/circle_collision_checker.py).  With more than a
+    few obstacle points they are sorted into a uniform cell index (cell >= robot radius) once, on the host, and every
+    pose tests the points of its 3 x 3 cells only: same predicate, same labels."""
+
+    INDEX_FROM = 32   # obstacle points from which the cell index pays
 
     def __init__(self, obstacle_points, robot_radius, boundaries=None, device="cuda"):
-        self.obstacles = torch.tensor(np.ascontiguousarray(obstacle_points, dtype=np.float32), device=device).reshape(-1, 2)
+        pts = np.ascontiguousarray(obstacle_points, dtype=np.float32).reshape(-1, 2)
         self.radius, self.boundaries = float(robot_radius), boundaries
+        self.cells = None
+        if len(pts) >= self.INDEX_FROM and self.radius > 0:
+            lo, hi = pts.min(0), pts.max(0)
+            # a little more than the radius: fp32 rounding of the cell arithmetic must not move a point two cells away
+            size = np.float32(max(self.radius * 1.001, float((hi - lo).max()) / 64.0))
+            nx, ny = (int(np.floor((hi[k] - lo[k]) / size)) + 1 for k in (0, 1))
+            # the kernel's own cell arithmetic (fp32 subtract, divide, floor), so points and poses agree on the cells
+            cx = np.clip(np.floor((pts[:, 0] - lo[0]) / size).astype(np.int64), 0, nx - 1)
+            cy = np.clip(np.floor((pts[:, 1] - lo[1]) / size).astype(np.int64), 0, ny - 1)
+            cell = cy * nx + cx
+            order = np.argsort(cell, kind="stable")
+            start = np.searchsorted(cell[order], np.arange(nx * ny + 1)).astype(np.int32)
+            pts = pts[order]
+            self.cells = (torch.tensor(start, device=device), nx, ny, float(lo[0]), float(lo[1]), float(size))
+        self.obstacles = torch.tensor(pts, device=device)
 
     def labels(self, poses, out=None):
         n, d = poses.shape
         out = torch.empty(n, dtype=torch.float32, device=poses.device) if out is None else out
         b = _f4(self.boundaries) if self.boundaries is not None else None
-        _lib.check(_lib.load().nfopp_check_collision_circle(_lib.ptr(poses), n, d, _lib.ptr(self.obstacles),
-                                                            self.obstacles.shape[0], self.radius, b, _lib.ptr(out),
-                                                            _lib.stream_ptr()))
+        lib = _lib.load()
+        if self.cells is None:
+            _lib.check(lib.nfopp_check_collision_circle(_lib.ptr(poses), n, d, _lib.ptr(self.obstacles),
+                                                        self.obstacles.shape[0], self.radius, b, _lib.ptr(out),
+                                                        _lib.stream_ptr()))
+        else:
+            start, nx, ny, x0, y0, size = self.cells
+            _lib.check(lib.nfopp_check_collision_circle_cells(_lib.ptr(poses), n, d, _lib.ptr(self.obstacles),
+                                                              self.obstacles.shape[0], _lib.ptr(start, torch.int32), nx, ny,
+                                                              x0, y0, size, self.radius, b, _lib.ptr(out), _lib.stream_ptr()))
         return out
 
 

@@ -136,3 +136,28 @@ def test_path_evaluation_and_early_stop_vs_oracle(D):
     best = planner.best_paths()
     assert best.shape == (B, N + 2, D)
     assert max_abs(best[~ref_col][:, 1:-1], traj0[~ref_col]) == 0
+
+
+def test_cell_indexed_circle_checker_equals_the_plain_one():
+    """300 discs (bench.py's map): the cell-indexed kernel must give the labels of the all-pairs kernel, which the
+    reference pins, on poses that include disc rims, map corners and far-away points."""
+    rng = np.random.default_rng(1234)
+    discs = rng.uniform(5, 95, (300, 2))
+    bounds = (0.0, 100.0, 0.0, 100.0)
+    fast = nfopp.DeviceCircleChecker(discs, 1.5, bounds)
+    assert fast.cells is not None
+    slow = nfopp.DeviceCircleChecker(discs, 1.5, bounds)
+    slow.cells = None
+    slow.obstacles = torch.tensor(discs.astype(F32), device="cuda")
+    rng = np.random.default_rng(7)
+    ang = rng.uniform(0, 2 * np.pi, 20000)
+    rim = discs[rng.integers(0, 300, 20000)] + (1.5 + rng.choice([-1e-4, 0, 1e-4, -1e-6, 1e-6], 20000))[:, None] * np.stack([np.cos(ang), np.sin(ang)], 1)
+    poses = np.concatenate([rng.uniform(-20, 120, (200000, 2)), rim, [[0, 0], [100, 100], [-1e6, 3], [50, 1e6]]]).astype(F32)
+    poses = np.concatenate([poses, np.zeros((len(poses), 1), F32)], 1)
+    p = torch.tensor(poses, device="cuda")
+    a, b = fast.labels(p).cpu().numpy(), slow.labels(p).cpu().numpy()
+    assert np.array_equal(a, b), (int((a != b).sum()), poses[a != b][:5])
+    assert 0.1 < a.mean() < 0.9
+    ref = orc.circle_check(poses[:, :2].astype(np.float64), discs.astype(F32).astype(np.float64), 1.5, bounds)
+    bad = a.astype(bool) != ref                       # float64 reference: only poses within fp32 rounding of a rim may differ
+    assert not bad[:200000].any() and not bad[-4:].any() and bad[200000:-4].mean() < 0.02
