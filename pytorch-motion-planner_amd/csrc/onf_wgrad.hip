@@ -166,43 +166,68 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
     for (int h = tid; h < NFOPP_HIDDEN; h += WG_THREADS) lds[W::L_W3A + hidden_slot(h, false)] = P[g.off_w3 + h];
   }
 
+  // Per-thread staging descriptors, computed ONCE: float4 number tid + k * WG_THREADS of a chunk always comes from the same
+  // array / column of sample q_k and goes to the same LDS place; from chunk to chunk only the sample index moves, by a
+  // fixed stride per array.  (Recomputing them per chunk -- 64-bit offsets, divisions by 115 -- was ~360 vector instructions
+  // per wave and chunk, and the fp32 MFMA shares the vector ALU: a quarter of the kernel.)
   f32x4 stage[W::F4_PER_THREAD];
+  const float* src[W::F4_PER_THREAD];   // source of this thread's k-th float4 for the NEXT prefetch
+  int src_step[W::F4_PER_THREAD];       // floats per chunk stride (KC * gridDim.x samples of that array's row length)
+  int dst[W::F4_PER_THREAD];            // LDS float offset inside a buffer; -1: nothing to stage
+  int qk[W::F4_PER_THREAD];             // sample of the chunk (for the ragged last chunk)
+#pragma unroll
+  for (int k = 0; k < W::F4_PER_THREAD; ++k) {
+    const int idx = tid + k * WG_THREADS;
+    src[k] = a.ws; src_step[k] = 0; dst[k] = -1; qk[k] = 0;
+    if (idx < KC * W::F4_PER_SAMPLE) {
+      const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
+      long long off; int col;
+      f4_source<NKT>(a.P, (long long)blockIdx.x * KC + q, c, &off, &col);
+      long long off1; int col1;
+      f4_source<NKT>(a.P, (long long)blockIdx.x * KC + q + 1, c, &off1, &col1);
+      src[k] = a.ws + off;
+      src_step[k] = (int)(off1 - off) * KC * (int)gridDim.x;   // row length of the array times samples per step
+      qk[k] = q;
+      dst[k] = col >= 0 ? q * W::STRIDE + col : (col == -1 ? W::B_RHO + q : W::B_MASK + 4 * q);
+      if (col == -1) dst[k] |= 1 << 30;                        // scalar store (rho)
+    }
+  }
   auto prefetch = [&](long long chunk) {
+    const long long left = a.P - chunk * KC;   // samples from the start of this chunk to the end
 #pragma unroll
     for (int k = 0; k < W::F4_PER_THREAD; ++k) {
-      const int idx = tid + k * WG_THREADS;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < KC * W::F4_PER_SAMPLE) {
-        const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
-        const long long p = chunk * KC + q;
-        if (p < a.P) {
-          long long src; int col;
-          f4_source<NKT>(a.P, p, c, &src, &col);
-          v = *reinterpret_cast<const f32x4*>(a.ws + src);
-        }
-      }
+      if (dst[k] >= 0 && qk[k] < left) v = *reinterpret_cast<const f32x4*>(src[k]);
       stage[k] = v;
+      src[k] += src_step[k];
     }
   };
   auto commit = [&](float* buf) {
 #pragma unroll
     for (int k = 0; k < W::F4_PER_THREAD; ++k) {
-      const int idx = tid + k * WG_THREADS;
-      if (idx < KC * W::F4_PER_SAMPLE) {
-        const int q = idx / W::F4_PER_SAMPLE, c = idx - q * W::F4_PER_SAMPLE;
-        long long src; int col;
-        f4_source<NKT>(0, 0, c, &src, &col);
-        if (col >= 0) *reinterpret_cast<f32x4*>(buf + q * W::STRIDE + col) = stage[k];
-        else if (col == -1) buf[W::B_RHO + q] = stage[k][0];
-        else *reinterpret_cast<f32x4*>(buf + W::B_MASK + 4 * q) = stage[k];
-      }
+      if (dst[k] < 0) continue;
+      if (dst[k] & (1 << 30)) buf[dst[k] & ~(1 << 30)] = stage[k][0];
+      else *reinterpret_cast<f32x4*>(buf + dst[k]) = stage[k];
     }
   };
-  // factors pass 1 did not store: in = features(u) with pass 1's arithmetic (features2), dh2 = rho * W3a * [a2 > 0]
+  // factors pass 1 did not store: in = features(u) with pass 1's arithmetic (features2), dh2 = rho * W3a * [a2 > 0].
+  // Item idx = tid + k * WG_THREADS (sample q, float4 c) is fixed per thread: its offsets are computed once.
+  constexpr int RB_ITEMS = (KC * W::REBUILD_F4 + WG_THREADS - 1) / WG_THREADS;
+  int rb_row[RB_ITEMS], rb_c[RB_ITEMS], rb_q[RB_ITEMS];
+#pragma unroll
+  for (int k = 0; k < RB_ITEMS; ++k) {
+    const int idx = tid + k * WG_THREADS;
+    const int q = idx / W::REBUILD_F4;
+    rb_q[k] = idx < KC * W::REBUILD_F4 ? q : -1;
+    rb_c[k] = idx - q * W::REBUILD_F4;
+    rb_row[k] = q * W::STRIDE;
+  }
   auto rebuild = [&](float* buf) {
-    for (int idx = tid; idx < KC * W::REBUILD_F4; idx += WG_THREADS) {
-      const int q = idx / W::REBUILD_F4, c = idx - q * W::REBUILD_F4;
-      float* row = buf + q * W::STRIDE;
+#pragma unroll
+    for (int k = 0; k < RB_ITEMS; ++k) {
+      if (rb_q[k] < 0) continue;
+      const int q = rb_q[k], c = rb_c[k];
+      float* row = buf + rb_row[k];
       if (c < HS / 4) {                       // dh2 slots 4c .. 4c+3: tile c >> 2, lane group c & 3
         const unsigned bits = __float_as_uint(buf[W::B_MASK + 4 * q + (c & 3)]) >> (4 * (c >> 2));
         const float rho = buf[W::B_RHO + q];
