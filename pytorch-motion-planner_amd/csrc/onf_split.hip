@@ -252,15 +252,34 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
     // ---------------------------------------------------------------- sample / load the wave's points
     float ux[NT], uy[NT], th[NT];
     long long pidx[NT];
-#pragma unroll
-    for (int tl = 0; tl < NT; ++tl) {
+#ifndef NFOPP_NO_SHARED_SAMPLING
+    if constexpr (NT == 2 && !TRAIN) {
+      // the four lane groups of a point column would each draw and interpolate BOTH tiles' samples (Philox, wrap, lerp):
+      // lane group g evaluates the sample of tile g & 1 once and the groups exchange the results
+      const int mine = g & 1;
       float x, y, ang;
-      pidx[tl] = load_point(a, n_work, chunk * CH + (wave * NT + tl) * 16 + i, g, x, y, ang);
-      ux[tl] = (x - geo.mean) / geo.sigma;
-      uy[tl] = (y - geo.mean) / geo.sigma;
-      th[tl] = ang;
-      if (TRAIN && g == 0 && pidx[tl] < a.n_points)
-        *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 12) = f32x4{ux[tl], uy[tl], 1.0f, ang};
+      const long long row = load_point(a, n_work, chunk * CH + (wave * NT + mine) * 16 + i, g >> 1, x, y, ang);
+      const float uxm = (x - geo.mean) / geo.sigma, uym = (y - geo.mean) / geo.sigma;
+      const int lo = (int)row, hi = (int)(row >> 32);
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) {
+        const int from = i + 16 * tl;   // a lane of group tl (g = tl: tile tl)
+        ux[tl] = __shfl(uxm, from); uy[tl] = __shfl(uym, from); th[tl] = __shfl(ang, from);
+        pidx[tl] = ((long long)__shfl(hi, from) << 32) | (unsigned)__shfl(lo, from);
+      }
+    } else
+#endif
+    {
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) {
+        float x, y, ang;
+        pidx[tl] = load_point(a, n_work, chunk * CH + (wave * NT + tl) * 16 + i, g, x, y, ang);
+        ux[tl] = (x - geo.mean) / geo.sigma;
+        uy[tl] = (y - geo.mean) / geo.sigma;
+        th[tl] = ang;
+        if (TRAIN && g == 0 && pidx[tl] < a.n_points)
+          *reinterpret_cast<f32x4*>(a.ws_u + pidx[tl] * 12) = f32x4{ux[tl], uy[tl], 1.0f, ang};
+      }
     }
 
     NFOPP_TICK(0)   // sampling
