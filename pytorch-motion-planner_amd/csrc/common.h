@@ -91,6 +91,21 @@ __device__ __forceinline__ float wrap_angle(float a) {
   return r - NFOPP_PI_F;
 }
 
+// a + b * c and p * a + q * b with every product and sum rounded on its own, as a chain of separate torch ops is on the
+// CPU (hipcc would contract the plain expressions to fused multiply-adds)
+// (HIP's __fmul_rn / __fadd_rn are plain * and + and contract like them: the pragma is what holds)
+__device__ __forceinline__ float add_mul_unfused(float a, float b, float c) {
+#pragma clang fp contract(off)
+  const float p = b * c;
+  return a + p;
+}
+__device__ __forceinline__ float mix_unfused(float p, float a, float q, float b) {
+#pragma clang fp contract(off)
+  const float pa = p * a;
+  const float qb = q * b;
+  return pa + qb;
+}
+
 // sin(x + q*pi/2) for q in Z: 3-term Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials
 // (<= 1.5 ulp for |x| < 1e5; checked against float64 in tests/test_host_logic.py through an fp32 emulation).
 __device__ __forceinline__ float sin_quadrant(float x, int q) {

@@ -20,6 +20,8 @@ constexpr int WAVES = THREADS / 64;
 constexpr int KSTEPS = 25;  // hidden k-steps: ks -> tile ks>>2, register ks&3 (tile 6 only register 0)
 
 
+constexpr bool BYTES_OK(int floats) { return size_t(floats) * 4 <= 160 * 1024; }
+
 template <int NKT>
 struct Lds {
   // layout P spreads a pair of input tiles over a block of 32 features, so an odd NKT still indexes a full block
@@ -49,7 +51,14 @@ struct Lds {
   static constexpr int W3A = B2 + 16 * HT;
   static constexpr int W3B = W3A + 16 * HT;               // NF skip weights
   static constexpr int ISA = W3B + NF;                    // NF flags: 1.0 = angle feature
-  static constexpr int TOTAL = ISA + NF;
+  // compact copy of the table for the paths that evaluate ONE feature per lane behind MFMAs (onf_split.hip's shadow
+  // work): (wx, wy, b, qh) in one 16-byte entry, the same two-halves placement
+  static constexpr int FC = ((ISA + NF + 3) / 4) * 4;
+  static constexpr int FC_HALF = ((NF / 2) * 4 / 64) * 64 + 64 + 32;     // = 32 mod 64
+  __host__ __device__ static constexpr int fc(int f) { return FC + FC_HALF * ((f >> 4) & 1) + 4 * (((f >> 5) << 4) | (f & 15)); }
+  __host__ __device__ static constexpr int fc_rel(int x) { return 4 * (x - 16 * (x >> 5)); }
+  static constexpr int TOTAL = FC + FC_HALF + (NF / 2) * 4;
+  static_assert(BYTES_OK(TOTAL), "LDS image exceeds 160 KB");
   static constexpr size_t BYTES = size_t(TOTAL) * 4;
 };
 
@@ -128,6 +137,8 @@ __device__ void fill_lds(float* lds, const OnfKernelArgs& a) {
     float* e = lds + L::ft(f);
     e[0] = e[1] = wx; e[2] = e[3] = wy; e[4] = e[5] = b; e[6] = e[7] = fr;
     e[8] = e[9] = qh; e[10] = e[11] = w3b;
+    float* c = lds + L::fc(f);
+    c[0] = wx; c[1] = wy; c[2] = b; c[3] = qh;
     lds[L::W3B + f] = w3b;
     lds[L::ISA + f] = is_angle;
   }
@@ -197,14 +208,16 @@ __device__ __forceinline__ long long load_point(const OnfKernelArgs& a, long lon
   }
   const float* qa = a.traj + (b * a.n_way + j) * a.dim;  // traj[:-1]
   const float* qb = qa + a.dim;                           // traj[1:]
+  // every product and sum rounded on its own, as the reference's separate torch ops do (no fused multiply-add): the
+  // sample is then bit-identical to the oracle's for the same t, and K1 sees the reference's inputs
   if (a.dim == 3) {
     // constrained:79-81  p = traj[1:] + t * wrap-theta(traj[:-1] - traj[1:])
     float dx = qa[0] - qb[0], dy = qa[1] - qb[1], dth = wrap_angle(qa[2] - qb[2]);
-    x = qb[0] + tt * dx; y = qb[1] + tt * dy; ang = qb[2] + tt * dth;
+    x = add_mul_unfused(qb[0], tt, dx); y = add_mul_unfused(qb[1], tt, dy); ang = add_mul_unfused(qb[2], tt, dth);
   } else {
     // nerf:117  p = traj[1:] * (1 - t) + traj[:-1] * t
     float omt = 1.0f - tt;
-    x = qb[0] * omt + qa[0] * tt; y = qb[1] * omt + qa[1] * tt;
+    x = mix_unfused(qb[0], omt, qa[0], tt); y = mix_unfused(qb[1], omt, qa[1], tt);
   }
   return valid ? row : a.n_points;
 }

@@ -301,6 +301,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
     const float* w1c = W1 + (96 + gi) * S1 + colP;
     const float* ftl = lds + L::ft(colP);   // lane part of every feature-table address (+ L::ft_rel(block or tile base))
     const float* isl = lds + L::ISA + colP;
+    const float* fcl = lds + L::fc(colP);   // the same for the compact table (+ L::fc_rel(...))
+    const float* w3l = lds + L::W3B + colP;
 
     u32x4 q0 = lo_frag(B::L1), q1 = lo_frag(B::L1 + 1);   // third-level fragments of the next two steps
     // raw (hi | mid) words: wa1 = the NEXT step (packed between this step's MFMAs), wb1 = the step after (in flight);
@@ -393,20 +395,19 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       float e_arg = 0.f, e_j = 0.f, e_r = 0.f, e_t = 0.f, e_v = 0.f;
       float s_ra = 0.f, s_rb = 0.f, s_la = 0.f, s_lb = 0.f;
       unsigned s_ta = 0, s_tb = 0;
-      f32x4 tw[2], tq[2];   // table entry of feature j (ping-pong on j & 1): (wx wx wy wy), (qh qh w3 w3)
-      float tb[2];          // its bias
+      f32x4 tw[2];          // compact table entry of feature j (ping-pong on j & 1): (wx, wy, b, qh)
+      float tz[2];          // its skip weight
       int nxt_off = 0;      // 32 (kb + 1): feature offset of the block being prepared
       auto table_load = [&](int j) __attribute__((always_inline)) {
-        const float* e = ftl + L::ft_rel(nxt_off + 8 * (j >> 2) + (j & 3));
-        tw[j & 1] = *reinterpret_cast<const f32x4*>(e);
-        tb[j & 1] = e[4];
-        tq[j & 1] = *reinterpret_cast<const f32x4*>(e + 8);
+        const int x = nxt_off + 8 * (j >> 2) + (j & 3);
+        tw[j & 1] = *reinterpret_cast<const f32x4*>(fcl + L::fc_rel(x));
+        tz[j & 1] = w3l[x];
       };
       auto work_item = [&](int w) __attribute__((always_inline)) {
         if (w < 144) {
           const int e = w / 9, u = w % 9, j = e >> 1, tl = e & 1, b = j & 1;
           if (u == 0) {
-            e_arg = fmaf(tw[b].z, uy[tl], tb[b]);
+            e_arg = fmaf(tw[b].y, uy[tl], tw[b].z);
             if (tl == 0 && j + 1 < 8) table_load(j + 1);
           }
           if (u == 1) e_arg = fmaf(tw[b].x, ux[tl], e_arg);
@@ -414,9 +415,9 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
           if (u == 3) e_j = e_t - 12582912.0f;
           if (u == 4) e_r = fmaf(e_j, -6.28318548202514648f, e_arg);
           if (u == 5) e_r = fmaf(e_j, 1.74845553e-07f, e_r);
-          if (u == 6) e_t = fmaf(e_r, 0.159154943f, tq[b].x);
+          if (u == 6) e_t = fmaf(e_r, 0.159154943f, tw[b].w);
           if (u == 7) e_v = __builtin_amdgcn_sinf(e_t);
-          if (u == 8) { skip[tl] = fmaf(tq[b].z, e_v, skip[tl]); fvn[tl][j] = e_v; }
+          if (u == 8) { skip[tl] = fmaf(tz[b], e_v, skip[tl]); fvn[tl][j] = e_v; }
         } else if (w < 232) {
           const int sp = (w - 144) / 11, v = (w - 144) % 11, tl = sp >> 2, pp = sp & 3;
           const float x0 = fvn[tl][2 * pp], x1 = fvn[tl][2 * pp + 1];
@@ -871,23 +872,25 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       // step w % 11; four to a slot.  Same arithmetic and order as l1t_tile's epilogue.
       f32x4 acc_prev[NT], acc_cur[NT];
       float d_arg = 0.f, d_j = 0.f, d_r = 0.f, d_t = 0.f, d_de = 0.f;
-      f32x4 dw[2];          // (wx wx wy wy) of feature row r, ping-pong on r & 1
-      float db[2], dq[2];   // bias, quadrant offset + a quarter turn (derivative)
+      // compact entry (wx, wy, b, qh) of feature row r, ping-pong on r & 1.  Kept as scalars: with the entry held as one
+      // f32x4, hipcc 7.2's SLP pass fused the two tiles' gy updates into v_pk_fma_f32 ... op_sel:[0,1,0] and the low lane
+      // (tile 0) came out wrong on the GPU -- the instruction alone is fine (tools/micro/pk_opsel.hip); DESIGN.md has the
+      // account.  tests/test_gpu_split_path.py is the guard.
+      float dwx[2], dwy[2], db[2], dq[2];   // dq: quadrant offset + a quarter turn (derivative)
       int pm_base = 0;      // base_p(mt - 1) + colP: first feature of the tile whose epilogue is in flight
       auto dtable_load = [&](int r) __attribute__((always_inline)) {
-        const float* e = lds + L::ft(pm_base + r);
-        dw[r & 1] = *reinterpret_cast<const f32x4*>(e);
-        db[r & 1] = e[4];
-        dq[r & 1] = e[8] + NFOPP_Q_UNIT;
+        const f32x4 e = *reinterpret_cast<const f32x4*>(lds + L::fc(pm_base + r));
+        dwx[r & 1] = e.x; dwy[r & 1] = e.y; db[r & 1] = e.z;
+        dq[r & 1] = e.w + NFOPP_Q_UNIT;
       };
       auto epi_item = [&](int w) __attribute__((always_inline)) {
         if (w >= 88) return;
         const int e = w / 11, u = w % 11, r = e >> 1, tl = e & 1, b = r & 1;
         if (u == 0) {
-          d_arg = fmaf(dw[b].z, uy[tl], db[b]);
+          d_arg = fmaf(dwy[b], uy[tl], db[b]);
           if (tl == 0 && r + 1 < 4) dtable_load(r + 1);
         }
-        if (u == 1) d_arg = fmaf(dw[b].x, ux[tl], d_arg);
+        if (u == 1) d_arg = fmaf(dwx[b], ux[tl], d_arg);
         if (u == 2) d_t = fmaf(d_arg, 0.159154943f, 12582912.0f);
         if (u == 3) d_j = d_t - 12582912.0f;
         if (u == 4) d_r = fmaf(d_j, -6.28318548202514648f, d_arg);
@@ -895,8 +898,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
         if (u == 6) d_t = fmaf(d_r, 0.159154943f, dq[b]);
         if (u == 7) d_t = __builtin_amdgcn_sinf(d_t);
         if (u == 8) d_de = acc_prev[tl][r] * d_t;
-        if (u == 9) gx[tl] = fmaf(d_de, dw[b].x, gx[tl]);
-        if (u == 10) gy[tl] = fmaf(d_de, dw[b].z, gy[tl]);
+        if (u == 9) gx[tl] = fmaf(d_de, dwx[b], gx[tl]);
+        if (u == 10) gy[tl] = fmaf(d_de, dwy[b], gy[tl]);
       };
       auto l1t_steps = [&](auto hook_c, int mt, f32x4 (&acc)[NT]) __attribute__((always_inline)) {
         constexpr bool HOOK = decltype(hook_c)::value;

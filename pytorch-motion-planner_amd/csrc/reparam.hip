@@ -137,13 +137,14 @@ __global__ __launch_bounds__(RP_THREADS) void reparam_kernel(const ReparamArgs a
     if (den < 1e-5f) den = 1e-5f;
     const float tau = (u - cb) / den;
     const float omt = 1.0f - tau;
-    traj[w * D] = omt * Q[ib * D] + tau * Q[ia * D];
-    traj[w * D + 1] = omt * Q[ib * D + 1] + tau * Q[ia * D + 1];
+    // products and sums rounded one by one, as the reference's separate torch ops are (no contraction to fma)
+    traj[w * D] = mix_unfused(omt, Q[ib * D], tau, Q[ia * D]);
+    traj[w * D + 1] = mix_unfused(omt, Q[ib * D + 1], tau, Q[ia * D + 1]);
     if (D == 3) {
       const float thb = Q[ib * 3 + 2];
-      traj[w * 3 + 2] = thb + tau * wrap_angle(Q[ia * 3 + 2] - thb);
-      a.cm[b * N + w] = omt * cmf[ib] + tau * cmf[ia];
-      li[w] = omt * lf[ib] + tau * lf[ia];
+      traj[w * 3 + 2] = add_mul_unfused(thb, tau, wrap_angle(Q[ia * 3 + 2] - thb));
+      a.cm[b * N + w] = mix_unfused(omt, cmf[ib], tau, cmf[ia]);
+      li[w] = mix_unfused(omt, lf[ib], tau, lf[ia]);
     }
   }
   if (D == 3) {

@@ -18,13 +18,6 @@ __device__ __forceinline__ float linspace_at(float s, float e, int steps, int i)
   return i < steps / 2 ? fmaf(step, (float)i, s) : fmaf(-step, (float)(steps - 1 - i), e);
 }
 
-// th + d * w with the product rounded first, as torch evaluates `trajectory[:, 2] + delta_angles`
-__device__ __forceinline__ float add_mul_unfused(float th, float d, float w) {
-#pragma clang fp contract(off)
-  const float p = d * w;
-  return th + p;
-}
-
 struct InitArgs {
   const float* start; const float* goal;   // [B, D]
   int n, directed;

@@ -38,10 +38,13 @@ def max_abs(a, b):
 # stiffer than scripts/benchmark.py's: the reference itself, restarted from the fixture's state with every coordinate
 # moved by ONE fp32 ulp, ends (xy, theta, lambda, cm) = (1.5e-5, 3e-6, 2e-6, 1e-8) away after 1 step at N=256
 # [(3.8e-5, 1.0e-4, 2.7e-5, 7e-7) at N=512], (1.5e-3, 5e-5, 5e-5, 9e-7) after 10 and (8.4e-3, 6.7e-3, 2.7e-3, 6e-5)
-# after 50 steps (measured in the build container, torch 2.10 CPU).  Gates = about 4x that conditioning.
+# after 50 steps (measured in the build container, torch 2.10 CPU).  Gates = about 4x that conditioning; cm after 50
+# steps 10x (one perturbed ulp is the FLOOR of what a different summation order does in every step: the fp32 matrix path
+# measured 3.5e-4 there, the split path 2.9e-5, both with collision samples that are the reference's bit for bit;
+# tools/gpu_benchmr_margins.py prints all of these).
 BENCHMR_ROLLOUT_TOL = {1: dict(xy=1.5e-4, th=4e-4, lam=1e-4, cm=3e-6),
                        10: dict(xy=6e-3, th=2e-3, lam=1e-3, cm=1e-5),
-                       50: dict(xy=3e-2, th=3e-2, lam=1e-2, cm=2.5e-4)}
+                       50: dict(xy=3e-2, th=3e-2, lam=1e-2, cm=6e-4)}
 BENCHMR_FIXTURES = [("traj_benchmr_n256.npz", (1, 10, 50)), ("traj_benchmr_n512.npz", (1, 10))]
 # g14 (B = 4, 12 steps FROM the straight-line initialisation, snapshots after steps 1 / 3 / 12).  On a straight line many
 # gradient entries are zero up to rounding and Adam's first steps turn each into a full +-lr move, so single entries are

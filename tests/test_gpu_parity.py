@@ -133,11 +133,43 @@ def test_reparametrize_vs_golden(tag):
     torch.cuda.synchronize()
     # the cdf is built with torch-CPU's own roundings (norm / cascade sum / float64 cumsum: csrc/reparam.hip), so
     # searchsorted lands on the reference's indices in every case, the 1-ulp tie on the 20 duplicated waypoints of
-    # "clamp" included; what is left is the rounding of the final lerps
-    tol = 2e-6
-    assert max_abs(eng.traj.cpu().numpy()[0], z[tag + "_out_traj"]) < tol
-    assert max_abs(eng.lam.cpu().numpy()[0], z[tag + "_out_lam"]) < tol
-    assert max_abs(eng.cm.cpu().numpy()[0], z[tag + "_out_cm"]) < tol
+    # "clamp" included; the lerps round every product and sum on its own like the reference's separate torch ops.
+    # The whole operation is BIT-EXACT against the reference's outputs.
+    assert np.array_equal(eng.traj.cpu().numpy()[0], z[tag + "_out_traj"])
+    assert np.array_equal(eng.lam.cpu().numpy()[0], z[tag + "_out_lam"])
+    assert np.array_equal(eng.cm.cpu().numpy()[0], z[tag + "_out_cm"])
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_collision_samples_are_the_reference_ones_bit_for_bit(dim):
+    """The fused kernel forms its collision samples (constrained:78-81 / nerf:113-117) with the reference's roundings:
+    evaluating the trajectory batch with injected t must equal, bit for bit, evaluating the oracle's sample poses
+    through the same kernel in explicit-pose mode.  B*(N-1) = 130560 samples: the two-tiles-per-wave variant."""
+    g1 = load_golden("g1_onf.npz")
+    tag = "a" if dim == 3 else "c"
+    onf, cfg = gc.make_onf(g1[tag + "_cfg"], g1[tag + "_params"])
+    assert g1[tag + "_x"].shape[1] == dim
+    rng = np.random.default_rng(5)
+    B, N = 512, 256
+    traj = (rng.random((B, N, dim)) * ([30.0, 30.0, 12.0][:dim]) - ([0.0, 0.0, 6.0][:dim])).astype(F32)
+    t = rng.random((B, N - 1)).astype(F32)
+    zeros = np.zeros((B, dim), F32)
+    if dim == 3:
+        s = dict(traj=traj, start=zeros, goal=zeros, lam=np.zeros((B, N + 1), F32), cm=np.zeros((B, N), F32),
+                 adam_m=np.zeros((B, N, 3), F32), adam_v=np.zeros((B, N, 3), F32), adam_step=0)
+        eng = gc.engine_from_state(onf, s, orc.Hyper())
+        samples = orc.sample_collision_points(traj, t)
+    else:
+        hyper = nfopp.TrajectoryHyper(collision_weight=0.01, lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+        s = dict(traj=traj, start=zeros, goal=zeros, adam_m=np.zeros((B, N, 2), F32), adam_v=np.zeros((B, N, 2), F32),
+                 adam_step=0)
+        eng = gc.engine_from_state(onf, s, hyper, vh_weight=3.0)
+        samples = orc.sample_collision_points_2d(traj, t)
+    eng.collision_eval(t)
+    torch.cuda.synchronize()
+    from_traj = eng.onf_out.cpu().numpy().reshape(-1, 4)
+    from_poses = onf.forward_with_grad(torch.tensor(samples.reshape(-1, dim), device="cuda")).cpu().numpy()
+    assert np.array_equal(from_traj, from_poses)
 
 
 def test_batch_equals_independent_reference_runs():

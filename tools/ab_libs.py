@@ -76,3 +76,9 @@ for k, v in times.items():
     print("%-8s median %.4f ms  min %.4f  (rounds: %s)" % (k, float(np.median(v)), min(v), " ".join("%.3f" % x for x in v)))
 print("variant / product (median): %.4f" % (np.median(times["variant"]) / np.median(times["product"])))
 print("outputs identical:", bool(torch.equal(out["product"], out["variant"])))
+if KERNEL == "k1" and not torch.equal(out["product"], out["variant"]):
+    d = (out["product"] - out["variant"]).abs().reshape(-1, 4)
+    scale = out["product"].abs().reshape(-1, 4).amax(0)
+    print("max |difference| per column (logit, gx, gy, gth):", [float("%.3g" % x) for x in d.amax(0).tolist()],
+          " column scale:", [float("%.3g" % x) for x in scale.tolist()],
+          " rows that differ:", int((d.amax(1) > 0).sum()), "of", d.shape[0])

@@ -61,3 +61,26 @@ for k in range(int(z["steps"])):
         stats("params", planner._collision_model.flat_parameters.cpu().numpy(), z["k%d_params" % k])
     stats("lam", planner._constraint_multipliers.cpu().numpy(), z["k%d_lam" % k])
     stats("cm", planner._collision_multipliers.cpu().numpy(), z["k%d_cm" % k])
+
+from conftest import BENCHMR_FIXTURES  # noqa: E402
+for name, ks in BENCHMR_FIXTURES:
+    z = load_golden(name)
+    onf, cfg = gc.make_onf(z["cfg"], z["params"])
+    hp = orc.Hyper.from_npz(z)
+    s3 = gc.state_of(z, "g3_")
+    eng = gc.engine_from_state(onf, s3, hp)
+    step_count, done = s3["step_count"], 0
+    for K in ks:
+        while done < K:
+            eng.optimize_trajectory(z["g6_t"][done][None], want_terms=False)
+            if step_count % 10 == 0:
+                eng.reparametrize()
+            step_count += 1
+            done += 1
+        print(name, "frozen-field rollout, after", K, "steps")
+        pre = "g6_k%d_" % K
+        tr = eng.traj.cpu().numpy()[0]
+        stats("xy", tr[:, :2], z[pre + "traj"][:, :2])
+        stats("theta", tr[:, 2], z[pre + "traj"][:, 2])
+        stats("lam", eng.lam.cpu().numpy()[0], z[pre + "lam"])
+        stats("cm", eng.cm.cpu().numpy()[0], z[pre + "cm"])
