@@ -324,6 +324,515 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
   }
 }
 
+// ---- pass 2 on the bf16 matrix pipe: three-level exact operand split, six partial products per fp32 multiply ---------
+// (the split matrix path, csrc/onf_split.hip's arithmetic: x = hi + mid + lo, products hh, hm, mh, hl, lh, mm -- every
+// dropped term is below 2^-24 of the product).  G1 and G2 carry 97 % of the flops and run as v_mfma_f32_16x16x32_bf16 with
+// K = 32 samples; G3 (de^T u, 4 useful columns) stays on the fp32 MFMA.
+//
+// LDS images.  Operands are stored SAMPLE-major as bf16, [32 samples][slots], one image per level, and read with the
+// transposing ds_read_b64_tr_b16: lane (i = l & 15, g = l >> 4) gets slot i of four sample rows per read, two reads make
+// the eight k values of its fragment.  Sample order inside a fragment: group g takes rows 16 (g >> 1) + 4 (g & 1) + {0..3}
+// and + 8 -- the same for A and B, so k pairs up -- which puts the 8 rows a 32-lane half reads at once next to each
+// other; with a row length of 8 * odd dwords they cover the 64 banks exactly once (conflict-free).  Staging threads split
+// each float4 once (11 vector instructions per pair) and store 8 bytes per level.
+//
+// Two phases per chunk, one barrier after each; each buffer is filled during the phase that multiplies out of the other:
+//   phase A(k): multiply G1(k) from bufA | stage into bufB: h1(k), dh2(k) (rebuilt from the record), de(k), u(k);
+//               record(k+1) -> record area
+//   phase B(k): multiply G2(k), G3(k) from bufB | stage into bufA: dh1(k+1), in(k+1) (re-evaluated from u(k+1))
+// Every HBM load is issued right after the registers it lands in were committed, two phases (about one chunk time) before
+// its use.  The staging of a phase is cut into seven pieces and each is issued behind one group of the phase's MFMAs: the
+// bf16 MFMA leaves the vector ALU free, so the splitting and the feature evaluation run in its shadow.
+constexpr int KS = 32;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int odd8(int dwords) { return ((dwords / 8) & 1) ? dwords : dwords + 8; }
+
+template <int NKT>
+struct WsLayout {   // all offsets in dwords
+  static constexpr int WIN = 16 * NKT;
+  static constexpr int R_H = odd8(HS / 2), R_IN = odd8(WIN / 2);      // row lengths of the bf16 images
+  static constexpr int P_H = KS * R_H, P_IN = KS * R_IN;              // one level of one operand
+  static constexpr int RS_DE = (WIN + 16) % 32 == 16 ? WIN + 16 : WIN + 32;   // fp32 rows  de | u tile, = 16 mod 32
+  static constexpr int A_DH1 = 0, A_IN = 3 * P_H, BUF_A = 3 * P_H + 3 * P_IN;
+  static constexpr int B_DH2 = BUF_A, B_H1 = B_DH2 + 3 * P_H, B_DE = B_H1 + 3 * P_H, BUF_END = B_DE + KS * RS_DE;
+  static constexpr int REC = BUF_END;                                  // two record areas [KS][12]
+  static constexpr int L_FT = REC + 2 * KS * 12, L_W3A = L_FT + 6 * WIN, L_TOTAL = L_W3A + HS;
+  static constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS image of the split weight-gradient pass");
+  static constexpr int NTILES = 8 * NKT + 49;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// x0, x1 -> (bf16 level of x0 | bf16 level of x1 << 16), residuals left in x0, x1
+__device__ __forceinline__ unsigned take_level(float& x0, float& x1) {
+  const unsigned t0 = __float_as_uint(x0) & 0xffff0000u, t1 = __float_as_uint(x1) & 0xffff0000u;
+  const unsigned w = __builtin_amdgcn_perm(t1, t0, 0x07060302);
+  x0 = x0 - __uint_as_float(t0);
+  x1 = x1 - __uint_as_float(t1);
+  return w;
+}
+// four consecutive slots of one sample -> 8 bytes per level at dword offset `at` of the three images starting at `img`
+__device__ __forceinline__ void store_split4(float* lds, int img, int plane, int at, f32x4 v) {
+  // `at` opaque: otherwise the compiler keeps one precomputed address register per (item, image) pair alive across the
+  // whole chunk loop (the images lie more than a 16-bit offset apart) and spills
+  asm volatile("" : "+v"(at));
+  u32x2 h, m, l;
+#ifdef NFOPP_ABL2_NO_SPLIT   /* development ablation: the three stores without the arithmetic */
+  h.x = __float_as_uint(v.x); h.y = __float_as_uint(v.y); m = h; l.x = __float_as_uint(v.z); l.y = __float_as_uint(v.w);
+  *reinterpret_cast<u32x2*>(lds + img + at) = h;
+  *reinterpret_cast<u32x2*>(lds + img + plane + at) = m;
+  *reinterpret_cast<u32x2*>(lds + img + 2 * plane + at) = l;
+  return;
+#endif
+  float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+  h.x = take_level(x0, x1); h.y = take_level(x2, x3);
+  m.x = take_level(x0, x1); m.y = take_level(x2, x3);
+  l.x = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302);   // third level: exact
+  l.y = __builtin_amdgcn_perm(__float_as_uint(x3), __float_as_uint(x2), 0x07060302);
+  *reinterpret_cast<u32x2*>(lds + img + at) = h;
+  *reinterpret_cast<u32x2*>(lds + img + plane + at) = m;
+  *reinterpret_cast<u32x2*>(lds + img + 2 * plane + at) = l;
+}
+
+// fragment of one level: two transposing reads (sample rows +0 and +8 of this lane group's set)
+template <int R>
+__device__ __forceinline__ s16x8 read_frag(const float* lane_base, int dword_off) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#ifdef NFOPP_ABL2_NO_FRAGREAD   /* development ablation */
+  return s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lane_base + dword_off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lane_base + dword_off + 8 * R));
+  return s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// Wait states between a group of MFMAs and vector instructions that may overwrite its operand registers (see the account in
+// DESIGN.md, "MFMA operand hazards"): hipcc 7.2 pads 7 after v_mfma_f32_16x16x32_bf16, which proved too few on MI355X.
+__device__ __forceinline__ void mfma_guard() {
+#ifndef NFOPP_NO_MFMA_GUARD
+  asm volatile("s_nop 15");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// Two tiles that share the A operand: the two accumulation chains are independent and alternate on the matrix pipe (a chain
+// alone waits for its own previous result every time).
+__device__ __forceinline__ void mfma_split_pair(const s16x8 (&a)[3], const s16x8 (&b0)[3], const s16x8 (&b1)[3], f32x4& c0,
+                                                f32x4& c1) {
+#ifdef NFOPP_ABL2_NO_MFMA
+  asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]));
+  return;
+#endif
+  c0 = mfma_bf16(a[2], b0[0], c0); c1 = mfma_bf16(a[2], b1[0], c1);
+  c0 = mfma_bf16(a[0], b0[2], c0); c1 = mfma_bf16(a[0], b1[2], c1);
+  c0 = mfma_bf16(a[1], b0[1], c0); c1 = mfma_bf16(a[1], b1[1], c1);
+  c0 = mfma_bf16(a[1], b0[0], c0); c1 = mfma_bf16(a[1], b1[0], c1);
+  c0 = mfma_bf16(a[0], b0[1], c0); c1 = mfma_bf16(a[0], b1[1], c1);
+  c0 = mfma_bf16(a[0], b0[0], c0); c1 = mfma_bf16(a[0], b1[0], c1);
+}
+// One tile: the three small products go to a side accumulator, so again two chains alternate; it is added at the end.
+__device__ __forceinline__ f32x4 mfma_split_single(const s16x8 (&a)[3], const s16x8 (&b)[3], f32x4 c) {
+#ifdef NFOPP_ABL2_NO_MFMA
+  asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+  return c;
+#endif
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  t = mfma_bf16(a[2], b[0], t); c = mfma_bf16(a[1], b[0], c);
+  t = mfma_bf16(a[0], b[2], t); c = mfma_bf16(a[0], b[1], c);
+  t = mfma_bf16(a[1], b[1], t); c = mfma_bf16(a[0], b[0], c);
+  return c + t;
+}
+// c += a * b for operands given as three levels (index 0 = hi): the six products above 2^-24, small ones first
+__device__ __forceinline__ f32x4 mfma_split(const s16x8 (&a)[3], const s16x8 (&b)[3], f32x4 c) {
+#ifdef NFOPP_ABL2_NO_MFMA   /* development ablation: operands are still read (kept alive), nothing multiplied */
+  asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+  return c;
+#endif
+  c = mfma_bf16(a[2], b[0], c);
+  c = mfma_bf16(a[0], b[2], c);
+  c = mfma_bf16(a[1], b[1], c);
+  c = mfma_bf16(a[1], b[0], c);
+  c = mfma_bf16(a[0], b[1], c);
+  c = mfma_bf16(a[0], b[0], c);
+  return c;
+}
+
+template <int NKT>
+__global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const WgradArgs a) {
+  using L = WsLayout<NKT>;
+  constexpr int WIN = L::WIN, H4 = HS / 4, W4 = WIN / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long n_chunks = (a.P + KS - 1) / KS;
+  const long long c0 = blockIdx.x, step = gridDim.x;
+
+  // ---- tables (slot order) and the constant parts of the images -----------------------------------------------------
+  {
+    const OnfGeom& g = a.geom;
+    const float* P = a.params;
+    for (int k = tid; k < L::L_TOTAL; k += WG_THREADS) lds[k] = 0.0f;   // also: u-tile columns 4..15, image pad columns
+    __syncthreads();
+    for (int f = tid; f < 32 * ((NKT + 1) / 2); f += WG_THREADS) {
+      const int slot = slot_layout_p(f);
+      if (slot >= WIN) continue;
+      float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, qh = 0.f, isa = 0.f;
+      if (f < g.n_enc) {
+        wx = P[g.off_we + 2 * f]; wy = P[g.off_we + 2 * f + 1];
+        b = g.off_be >= 0 ? P[g.off_be + f] : 0.0f;
+        qh = (g.n_enc > g.n_sin && f >= g.n_sin) ? NFOPP_Q_UNIT : 0.0f;
+      } else if (f < g.fin) {
+        const int k = f - g.n_enc;
+        b = P[g.off_ang_b + k]; fr = P[g.off_ang_f + k];
+        qh = k >= g.ang_dim ? NFOPP_Q_UNIT : 0.0f;
+        isa = 1.0f;
+      } else if (f == a.aug_feature) {
+        qh = NFOPP_Q_UNIT;
+      }
+      float* e = lds + L::L_FT + slot;
+      e[0] = wx; e[WIN] = wy; e[2 * WIN] = b; e[3 * WIN] = fr; e[4 * WIN] = qh; e[5 * WIN] = isa;
+    }
+    for (int h = tid; h < NFOPP_HIDDEN; h += WG_THREADS) lds[L::L_W3A + hidden_slot(h, false)] = P[g.off_w3 + h];
+  }
+  __syncthreads();   // the tables are read into registers below
+
+  // ---- staging descriptors, fixed per thread (item = one float4 of one sample of the chunk) --------------------------
+  // array X with row4 float4 per sample: item idx = tid + j * 512 -> sample q = idx / row4, float4 c = idx % row4
+  constexpr int N_H = (KS * H4 + WG_THREADS - 1) / WG_THREADS, N_W = (KS * W4 + WG_THREADS - 1) / WG_THREADS;
+  f32x4 st_dh1[N_H], st_h1[N_H], st_de[N_W], st_rec;
+  // (sample q << 8 | float4 c) of the items.  Unpacked through an opaque copy at every use: left to itself the compiler
+  // keeps a dozen derived offsets per item alive across the chunk loop and spills them.
+  int hqc[N_H], wqc[N_W];
+#pragma unroll
+  for (int j = 0; j < N_H; ++j) {
+    const int idx = tid + j * WG_THREADS;
+    const int it = idx < KS * H4 ? idx : KS * H4 - 1;   // surplus threads repeat the last item (same data, same place)
+    hqc[j] = ((it / H4) << 8) | (it % H4);
+  }
+#pragma unroll
+  for (int j = 0; j < N_W; ++j) {
+    const int idx = tid + j * WG_THREADS;
+    const int it = idx < KS * W4 ? idx : KS * W4 - 1;
+    wqc[j] = ((it / W4) << 8) | (it % W4);
+  }
+  auto unpack = [](int qc, int& q, int& c) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(qc));
+    q = qc >> 8;
+    c = qc & 255;
+  };
+  const int rit = tid < KS * 3 ? tid : KS * 3 - 1, rq = rit / 3, rc = rit % 3;   // record: 3 float4 per sample
+  const float* const ws_h1 = a.ws;
+  const float* const ws_dh1 = a.ws + a.P * HS;
+  const float* const ws_de = a.ws + a.P * 2 * HS;
+  const float* const ws_rec = a.ws + a.P * (2 * HS + WIN);
+  // HBM loads as raw buffer loads: one resource per array and chunk (base = the chunk's first row, size = the rows that exist),
+  // so the per-item offset q * row + 16 c is a 32-bit chunk-invariant and rows past P -- and the idle items, whose offset is
+  // negative -- read as zeros without a branch
+  auto chunk_rsrc = [&](const float* base, long long chunk, int row_floats) __attribute__((always_inline)) {
+    const long long p0 = chunk * KS;
+    long long rows = a.P - p0;
+    rows = rows > KS ? KS : (rows < 0 ? 0 : rows);
+    const float* ptr = base + (rows > 0 ? p0 : 0) * row_floats;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(rows * row_floats * 4), 0x00020000);
+  };
+  auto load_h = [&](const float* base, f32x4 (&st)[N_H], long long chunk) __attribute__((always_inline)) {
+    const auto rsrc = chunk_rsrc(base, chunk, HS);
+#pragma unroll
+    for (int j = 0; j < N_H; ++j) {
+      int q, c;
+      unpack(hqc[j], q, c);
+      st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (HS * 4) + 16 * c, 0, 0));
+    }
+  };
+  auto load_de = [&](long long chunk) __attribute__((always_inline)) {
+    const auto rsrc = chunk_rsrc(ws_de, chunk, WIN);
+#pragma unroll
+    for (int j = 0; j < N_W; ++j) {
+      int q, c;
+      unpack(wqc[j], q, c);
+      st_de[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (WIN * 4) + 16 * c, 0, 0));
+    }
+  };
+  auto load_rec = [&](long long chunk) __attribute__((always_inline)) {
+    const auto rsrc = chunk_rsrc(ws_rec, chunk, 12);
+    st_rec = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rq * 48 + 16 * rc, 0, 0));
+  };
+  auto commit_rec = [&](int parity) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(lds + L::REC + parity * KS * 12 + rq * 12 + 4 * rc) = st_rec;
+  };
+  // The staging work of a phase is cut into seven pieces, one behind each group of MFMAs of the phase that multiplies out
+  // of the OTHER buffer (the bf16 MFMA leaves the vector ALU free: the pieces run in its shadow).
+  auto commit_h1 = [&](int img, const f32x4& v, int qc) __attribute__((always_inline)) {
+    int q, c;
+    unpack(qc, q, c);
+    store_split4(lds, img, L::P_H, q * L::R_H + 2 * c, v);
+  };
+  auto commit_de1 = [&](int j) __attribute__((always_inline)) {
+    int q, c;
+    unpack(wqc[j], q, c);
+    *reinterpret_cast<f32x4*>(lds + L::B_DE + q * L::RS_DE + 4 * c) = st_de[j];
+  };
+  // Rebuilt operands.  A thread's items keep their columns from chunk to chunk, so the table entries they need are loaded
+  // into registers ONCE (the LDS reads and their latency were most of the staging time at two waves per SIMD):
+  //  * dh2: item j of the hidden-side list (sample q, float4 c) -> W3a[4c .. 4c+3];
+  //  * in:  thread t < T_I owns slot quad s4 = t % W4 for the samples q = t / W4 + SP * j -> one table entry (24 floats).
+  f32x4 w3a_reg[N_H];
+#pragma unroll
+  for (int j = 0; j < N_H; ++j) w3a_reg[j] = *reinterpret_cast<const f32x4*>(lds + L::L_W3A + 4 * (hqc[j] & 255));
+  constexpr int SP = WG_THREADS / W4, T_I = SP * W4, N_I = (KS + SP - 1) / SP;
+  static_assert(N_I <= 4, "four feature-rebuild pieces per phase");
+  const int it_in = tid < T_I ? tid : tid - T_I;      // surplus threads repeat other owners' work (same data, same place:
+                                                      // no branch in the staging pieces, which interleave with MFMAs)
+  const int in_s4 = it_in % W4, in_q0 = it_in / W4;
+  f32x4 t_wx, t_wy, t_b, t_fr, t_qh, t_isa;
+  {
+    const float* e = lds + L::L_FT + 4 * in_s4;
+    t_wx = *reinterpret_cast<const f32x4*>(e); t_wy = *reinterpret_cast<const f32x4*>(e + WIN);
+    t_b = *reinterpret_cast<const f32x4*>(e + 2 * WIN); t_fr = *reinterpret_cast<const f32x4*>(e + 3 * WIN);
+    t_qh = *reinterpret_cast<const f32x4*>(e + 4 * WIN); t_isa = *reinterpret_cast<const f32x4*>(e + 5 * WIN);
+  }
+  auto rebuild_dh2 = [&](const float* rec, int j) __attribute__((always_inline)) {
+    int q, c;     // dh2 slots 4c .. 4c+3 = rho * W3a * [a2 > 0]: tile c >> 2, lane group c & 3
+    unpack(hqc[j], q, c);
+    const unsigned bits = __float_as_uint(rec[q * 12 + 8 + (c & 3)]) >> (4 * (c >> 2));
+    const float rho = rec[q * 12 + 4];
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ((bits >> r) & 1u) ? w3a_reg[j][r] * rho : 0.0f;
+    store_split4(lds, L::B_DH2, L::P_H, q * L::R_H + 2 * c, v);
+  };
+  auto rebuild_in = [&](const float* rec, int j) __attribute__((always_inline)) {
+    int q = in_q0 + SP * j;   // in slots 4 s4 .. 4 s4 + 3 of sample q = features(u), pass 1's arithmetic
+    q = q < KS ? q : KS - 1;
+    asm volatile("" : "+v"(q));
+    const f32x2 ux = splat2(rec[q * 12]), uy = splat2(rec[q * 12 + 1]), th = splat2(rec[q * 12 + 3]);
+    f32x4 v;
+#ifdef NFOPP_ABL2_NO_FEAT   /* development ablation */
+    v = f32x4{ux.x, uy.x, th.x, ux.x};
+#else
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x2 o = features2<true, false>(f32x2{t_wx[2 * h], t_wx[2 * h + 1]}, f32x2{t_wy[2 * h], t_wy[2 * h + 1]},
+                                             f32x2{t_b[2 * h], t_b[2 * h + 1]}, f32x2{t_fr[2 * h], t_fr[2 * h + 1]},
+                                             f32x2{t_qh[2 * h], t_qh[2 * h + 1]}, f32x2{t_isa[2 * h], t_isa[2 * h + 1]},
+                                             ux, uy, th);
+      v[2 * h] = o.x; v[2 * h + 1] = o.y;
+    }
+#endif
+    store_split4(lds, L::A_IN, L::P_IN, q * L::R_IN + 2 * in_s4, v);
+  };
+  static_assert(N_H == 2 && N_W <= 4, "the piece lists below are written for two hidden-side and up to four input-side items");
+  // piece i of phase A's staging (into bufB: h1, de, u, dh2 of the chunk whose record area is `parity`; record of the next
+  // chunk; loads of the chunk after)
+  auto stage_b = [&](auto piece_c, int parity, long long chunk) __attribute__((always_inline)) {
+    constexpr int piece = decltype(piece_c)::value;
+    const float* rec = lds + L::REC + parity * KS * 12;
+#ifdef NFOPP_ABL2_NO_STAGE   /* development ablation: loads only */
+    if constexpr (piece == 6) { load_rec(chunk + 2 * step); load_h(ws_h1, st_h1, chunk + step); load_de(chunk + step); }
+    return;
+#endif
+    if constexpr (piece == 0) { commit_rec(parity ^ 1); commit_h1(L::B_H1, st_h1[0], hqc[0]); }
+    if constexpr (piece == 1) commit_h1(L::B_H1, st_h1[1], hqc[1]);
+    if constexpr (piece == 2) { commit_de1(0); if (N_W > 1) commit_de1(1 < N_W ? 1 : 0); }
+    if constexpr (piece == 3) {
+      if (N_W > 2) commit_de1(2 < N_W ? 2 : 0);
+      if (N_W > 3) commit_de1(3 < N_W ? 3 : 0);
+      { const int t = tid & (KS * 4 - 1); lds[L::B_DE + (t >> 2) * L::RS_DE + WIN + (t & 3)] = rec[(t >> 2) * 12 + (t & 3)]; }
+    }
+    if constexpr (piece == 4) rebuild_dh2(rec, 0);
+    if constexpr (piece == 5) rebuild_dh2(rec, 1);
+#ifndef NFOPP_ABL2_NO_LOADS
+    if constexpr (piece == 6) { load_rec(chunk + 2 * step); load_h(ws_h1, st_h1, chunk + step); load_de(chunk + step); }
+#endif
+  };
+  // piece i of phase B's staging (into bufA: dh1 and in = features(u) of the NEXT chunk, record area `parity`)
+  auto stage_a = [&](auto piece_c, int parity, long long chunk) __attribute__((always_inline)) {
+    constexpr int piece = decltype(piece_c)::value;
+    const float* rec = lds + L::REC + parity * KS * 12;
+#ifdef NFOPP_ABL2_NO_STAGE
+    if constexpr (piece == 6) load_h(ws_dh1, st_dh1, chunk + 2 * step);
+    return;
+#endif
+    if constexpr (piece == 0) commit_h1(L::A_DH1, st_dh1[0], hqc[0]);
+    if constexpr (piece == 1) commit_h1(L::A_DH1, st_dh1[1], hqc[1]);
+    if constexpr (piece >= 2 && piece <= 5) { if (piece - 2 < N_I) rebuild_in(rec, piece - 2); }
+#ifndef NFOPP_ABL2_NO_LOADS
+    if constexpr (piece == 6) load_h(ws_dh1, st_dh1, chunk + 2 * step);
+#endif
+  };
+
+  // ---- this wave's output tiles -------------------------------------------------------------------------------------
+  // G1 (7 x NKT tiles, dh1^T in): column blocks 2w, 2w+1 for waves 0..5, 12 + (w - 6) for waves 6, 7; all 7 row blocks.
+  // G2 (7 x 7, dh2^T h1): waves 6, 7 take column blocks {0,1} / {2,3}; waves 0..5 column block 4 + (w >> 1), row blocks
+  //   0..3 (even w) or 4..6 (odd w).   G3 (NKT x 1, de^T u, fp32): row blocks w, w + 6, w + 12 of waves 0..5.
+  // 21 accumulator tiles either way: "wide" waves 0..5 = 14 G1 + 4 G2 + 3 G3, waves 6, 7 = 7 G1 + 14 G2; the two kinds run
+  // two instantiations of the same body (static accumulator indices).
+  // lane part of every transposing read: row (set of this lane group) + q, dwords 2p of the block's 8
+  const int grp = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, i16 = lane & 15;
+  const int row0 = 16 * (grp >> 1) + 4 * (grp & 1) + qq;
+  const int lane_h = row0 * L::R_H + 2 * pp, lane_in = row0 * L::R_IN + 2 * pp;
+
+  auto body = [&](auto wide_c) __attribute__((always_inline)) {
+    constexpr bool WIDE = decltype(wide_c)::value;
+    constexpr int NC1 = WIDE ? 2 : 1, NC2 = WIDE ? 1 : 2, NR2 = WIDE ? 4 : 7;
+    const int g1_cb = WIDE ? 2 * wave : 12 + (wave - 6);
+    const int g2_cb = WIDE ? 4 + (wave >> 1) : 2 * (wave - 6);
+    const int g2_rb0 = WIDE ? 4 * (wave & 1) : 0;
+    // one base register per image, with this wave's column / first row block folded in: every read offset below is a
+    // compile-time constant under 64 KB and goes into the instruction's offset field
+    const float* const bA_dh1 = lds + L::A_DH1 + lane_h;
+    const float* const bA_in = lds + L::A_IN + lane_in + 8 * g1_cb;
+    const float* const bB_dh2 = lds + L::B_DH2 + lane_h + 8 * g2_rb0;
+    const float* const bB_h1 = lds + L::B_H1 + lane_h + 8 * g2_cb;
+    f32x4 acc1[NC1][7], acc2[NC2][NR2], acc3[3];
+#pragma unroll
+    for (int c = 0; c < NC1; ++c)
+#pragma unroll
+      for (int r = 0; r < 7; ++r) acc1[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC2; ++c)
+#pragma unroll
+      for (int r = 0; r < NR2; ++r) acc2[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // hook(i), i = 0..6: one piece of the other buffer's staging, issued as a block behind the MFMAs of step i.  (Dealing the
+    // piece's instructions out BETWEEN the MFMAs with sched_group_barrier gained 2 % and made the result differ from run to
+    // run on the GPU -- a hazard between the 8-pass MFMA and neighbouring vector instructions that hipcc 7.2 does not pad;
+    // the block form is bitwise reproducible, tests/test_gpu_benchmr.py checks it at full size.)
+    auto mul_g1 = [&](auto&& hook) __attribute__((always_inline)) {
+      s16x8 bf[NC1][3];
+#pragma unroll
+      for (int c = 0; c < NC1; ++c)
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) bf[c][lv] = read_frag<L::R_IN>(bA_in, lv * L::P_IN + 8 * c);
+      s16x8 af[3], an[3];
+#pragma unroll
+      for (int lv = 0; lv < 3; ++lv) af[lv] = read_frag<L::R_H>(bA_dh1, lv * L::P_H);
+      static_for<0, 7>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r + 1 < 7)
+#pragma unroll
+          for (int lv = 0; lv < 3; ++lv) an[lv] = read_frag<L::R_H>(bA_dh1, lv * L::P_H + 8 * (r + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NC1 == 2) mfma_split_pair(af, bf[0], bf[1], acc1[0][r], acc1[1][r]);
+        else acc1[0][r] = mfma_split_single(af, bf[0], acc1[0][r]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_guard();
+        hook(rc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) af[lv] = an[lv];
+      });
+    };
+    // G2 (+ G3 on the wide waves): 7 steps as well -- wide: 4 row blocks of G2, then 3 tiles of G3; narrow: 7 row blocks
+    auto mul_g23 = [&](auto&& hook) __attribute__((always_inline)) {
+      s16x8 bf[NC2][3];
+#pragma unroll
+      for (int c = 0; c < NC2; ++c)
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) bf[c][lv] = read_frag<L::R_H>(bB_h1, lv * L::P_H + 8 * c);
+      // odd wide waves: row blocks 4, 5, 6 and an idle slot that reads past block 6 into the next sample row (in the image,
+      // never stored)
+      s16x8 af[3], an[3];
+#pragma unroll
+      for (int lv = 0; lv < 3; ++lv) af[lv] = read_frag<L::R_H>(bB_dh2, lv * L::P_H);
+      const float* rowk = lds + L::B_DE + grp * L::RS_DE + i16;
+      static_for<0, 7>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r < NR2) {
+          if constexpr (r + 1 < NR2)
+#pragma unroll
+            for (int lv = 0; lv < 3; ++lv) an[lv] = read_frag<L::R_H>(bB_dh2, lv * L::P_H + 8 * (r + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (NC2 == 2) mfma_split_pair(af, bf[0], bf[1], acc2[0][r], acc2[1][r]);
+          else acc2[0][r] = mfma_split_single(af, bf[0], acc2[0][r]);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_guard();
+          hook(rc);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int lv = 0; lv < 3; ++lv) af[lv] = an[lv];
+        } else {                         // wide waves, steps 4..6: G3 tile j = r - 4 (fp32 MFMA, K = 4 samples per step)
+          constexpr int j = r - NR2;
+          const int rb = wave + 6 * j;
+          if (rb < NKT) {
+#pragma unroll
+            for (int s = 0; s < KS / 4; ++s)
+              acc3[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rowk[4 * s * L::RS_DE + 16 * rb], rowk[4 * s * L::RS_DE + WIN],
+                                                             acc3[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_guard();
+          hook(rc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    };
+
+    // ---- pipeline ----------------------------------------------------------------------------------------------------
+    // prologue: record(c0) and bufA(c0) in place, record(c0 + step), dh1(c0 + step) and h1 / de (c0) in registers
+    if (c0 < n_chunks) {
+      load_rec(c0);
+      load_h(ws_dh1, st_dh1, c0);
+      commit_rec(0);
+      load_rec(c0 + step);                      // past P: zeros
+      load_h(ws_h1, st_h1, c0);
+      load_de(c0);
+      __syncthreads();
+      static_for<0, 6>([&](auto pc) __attribute__((always_inline)) { stage_a(pc, 0, c0); });
+      load_h(ws_dh1, st_dh1, c0 + step);
+      __syncthreads();
+    }
+    int parity = 0;                             // record area of the chunk being multiplied
+    for (long long chunk = c0; chunk < n_chunks; chunk += step) {
+      mul_g1([&](auto pc) __attribute__((always_inline)) { stage_b(pc, parity, chunk); });         // phase A
+      __syncthreads();
+      mul_g23([&](auto pc) __attribute__((always_inline)) { stage_a(pc, parity ^ 1, chunk); });    // phase B
+      __syncthreads();
+      parity ^= 1;
+    }
+
+    // ---- per-workgroup partial tiles (tile numbering and element order of the fp32 kernel) ------------------------------
+    auto put = [&](int T, const f32x4& v) __attribute__((always_inline)) {
+      float* o = a.partial + ((long long)blockIdx.x * L::NTILES + T) * 256 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[64 * r] = v[r];
+    };
+#pragma unroll
+    for (int c = 0; c < NC1; ++c)
+      if (g1_cb + c < NKT)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) put(r * NKT + g1_cb + c, acc1[c][r]);
+#pragma unroll
+    for (int c = 0; c < NC2; ++c)
+#pragma unroll
+      for (int r = 0; r < NR2; ++r)
+        if (g2_rb0 + r < 7) put(7 * NKT + (g2_rb0 + r) * 7 + g2_cb + c, acc2[c][r]);
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (wave + 6 * j < NKT) put(7 * NKT + 49 + wave + 6 * j, acc3[j]);
+    }
+  };
+  if (wave < 6) body(std::true_type{});
+  else body(std::false_type{});
+}
+
 // reduced[e] = sum over workgroups of partial[wg][e], fixed order
 __global__ __launch_bounds__(256) void onf_wgrad_reduce_kernel(const float* partial, float* reduced, int n_elems, int n_wg) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -448,6 +957,18 @@ static int launch_wgrad(const WgradArgs& a, int grid, hipStream_t st) {
   return NFOPP_OK;
 }
 
+template <int NKT>
+static int launch_wgrad_split(const WgradArgs& a, int grid, hipStream_t st) {
+  using L = WsLayout<NKT>;
+  static bool attr_set[MAX_DEVICES] = {};
+  auto kern = onf_wgrad_split_kernel<NKT>;
+  const int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L::LDS_BYTES, attr_set);
+  if (rc_attr != NFOPP_OK) return rc_attr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG_THREADS), L::LDS_BYTES, st, a);
+  NFOPP_HIP(hipGetLastError());
+  return NFOPP_OK;
+}
+
 // gradient of the mean BCE loss over `count` samples (inv_count = 1 / count) into grad[n_params + 2]
 int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samples, const float* labels, long long P,
                         float inv_count, float* grad, float* ws, hipStream_t st) {
@@ -467,13 +988,15 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
   WgradArgs wa;
   wa.geom = g; wa.params = params; wa.aug_feature = aug;
   wa.ws = ws + w.h1; wa.P = P; wa.partial = ws + w.partial;   // arrays back to back from w.h1 (see carve_wgrad)
-  long long n_chunks = (P + KC - 1) / KC;
+  const bool split = onf_split_enabled();   // pass 2 follows pass 1's matrix path
+  const int kc = split ? KS : KC;
+  long long n_chunks = (P + kc - 1) / kc;
   int grid = (int)(n_chunks < w.grid_cap ? n_chunks : w.grid_cap);
   switch (nkt) {
-    case 14: rc = launch_wgrad<14>(wa, grid, st); break;
-    case 13: rc = launch_wgrad<13>(wa, grid, st); break;
-    case 8: rc = launch_wgrad<8>(wa, grid, st); break;
-    case 7: rc = launch_wgrad<7>(wa, grid, st); break;
+    case 14: rc = split ? launch_wgrad_split<14>(wa, grid, st) : launch_wgrad<14>(wa, grid, st); break;
+    case 13: rc = split ? launch_wgrad_split<13>(wa, grid, st) : launch_wgrad<13>(wa, grid, st); break;
+    case 8: rc = split ? launch_wgrad_split<8>(wa, grid, st) : launch_wgrad<8>(wa, grid, st); break;
+    case 7: rc = split ? launch_wgrad_split<7>(wa, grid, st) : launch_wgrad<7>(wa, grid, st); break;
     default: set_error("unsupported ONF feature dimension %d", g.fin); return NFOPP_ERR_ARG;
   }
   if (rc) return rc;

@@ -306,3 +306,23 @@ def test_continuous_learning_full_size_and_two_shard_gradient():
     scale = float(np.abs(g_full[:-2]).max())
     assert max_abs(g_sum[:-2], g_full[:-2]) < 2e-5 * scale                # summation order only
     assert abs(g_sum[-2] - g_full[-2]) < 1e-5 * abs(g_full[-2])           # global mean loss
+
+
+def test_fit_gradient_repeats_bit_for_bit():
+    """The full-size ONF fit gradient (2 543 616 samples: pass 1 + the weight-gradient pass + fixed-order reductions), repeated 24
+    times on the same inputs, must come out bit for bit the same.  Guards the wait states between the 8-pass bf16 MFMAs and
+    the vector instructions that reuse their registers in csrc/onf_wgrad.hip (`mfma_guard`): without them two of three
+    processes saw single repeats differ in the 7th digit -- a timing-dependent operand hazard, not an arithmetic one."""
+    z = load_golden("traj_benchmr_n512.npz")
+    onf, cfg = gc.make_onf(z["cfg"], z["params"])
+    P = 4096 * 621
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(P, 3, device="cuda", generator=gen) * torch.tensor([100.0, 100.0, 6.28], device="cuda")
+    y = (torch.rand(P, device="cuda", generator=gen) < 0.35).float()
+    fit = nfopp.OnfFitter(onf, 2e-2, (0.9, 0.9), distributed=False)
+    fit._hip_grad(x, y, 1.0 / P)
+    first = fit.grad.clone()
+    assert torch.isfinite(first).all()
+    for _ in range(24):
+        fit._hip_grad(x, y, 1.0 / P)
+        assert torch.equal(fit.grad, first)
