@@ -415,8 +415,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
           if (u == 3) e_j = e_t - 12582912.0f;
           if (u == 4) e_r = fmaf(e_j, -6.28318548202514648f, e_arg);
           if (u == 5) e_r = fmaf(e_j, 1.74845553e-07f, e_r);
-          if (u == 6) e_t = fmaf(e_r, 0.159154943f, tw[b].w);
-          if (u == 7) e_v = __builtin_amdgcn_sinf(e_t);
+          if (u == 6) e_v = fmaf(e_r, 0.159154943f, tw[b].w);
+          if (u == 7) e_v = __builtin_amdgcn_sinf(e_v);   // the argument is formed in e_v (source = destination)
           if (u == 8) { skip[tl] = fmaf(tz[b], e_v, skip[tl]); fvn[tl][j] = e_v; }
         } else if (w < 232) {
           const int sp = (w - 144) / 11, v = (w - 144) % 11, tl = sp >> 2, pp = sp & 3;

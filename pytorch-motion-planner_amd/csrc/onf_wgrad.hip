@@ -106,6 +106,23 @@ __device__ __forceinline__ void f4_source(long long P, long long p, int c, long 
   if (c > t3) *col = -(c - t3);   // -1: rho quad, -2: the four sign words
 }
 
+// Four input features of one sample from its pose, scalar form of features2<true, false> (same operations in the same order,
+// so the values are the ones pass 1 used).  Scalar on purpose: the pose has just been read from LDS, and the packed form let
+// hipcc fold the splat of u_y into  v_pk_fma_f32 ... op_sel:[0,1,0]  on the freshly loaded register pair, whose LOW lane then
+// sometimes saw the previous sample's u_y on MI355X ("A hazard hipcc does not pad").
+__device__ __forceinline__ f32x4 features4_scalar(const f32x4& wx, const f32x4& wy, const f32x4& b, const f32x4& fr, const f32x4& qh,
+                                                  const f32x4& isa, float ux, float uy, float th) {
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float arg = fmaf(wx[k], ux, fmaf(wy[k], uy, b[k]));   // encoding_layer: W_e u + b_e (onf_model.py:39)
+    const float za = (th + b[k]) * fr[k];                  // (theta + b) * f (angle_encoder.py:16)
+    arg = isa[k] != 0.0f ? za : arg;
+    v[k] = sin_halfturns_hw(arg, qh[k]);
+  }
+  return v;
+}
+
 template <int NKT>
 __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArgs a) {
   using W = WgLayout<NKT>;
@@ -238,19 +255,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
         *reinterpret_cast<f32x4*>(row + W::C_DH2 + 4 * c) = v;
       } else {                                // in slots 4s .. 4s+3
         const int s4 = c - HS / 4;
-        const f32x2 ux = splat2(row[W::C_U]), uy = splat2(row[W::C_U + 1]), th = splat2(row[W::C_U + 3]);
+        const float ux = row[W::C_U], uy = row[W::C_U + 1], th = row[W::C_U + 3];
         const float* e = lds + W::L_FT + 4 * s4;
         const f32x4 wx = *reinterpret_cast<const f32x4*>(e), wy = *reinterpret_cast<const f32x4*>(e + W::WIN);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(e + 2 * W::WIN), fr = *reinterpret_cast<const f32x4*>(e + 3 * W::WIN);
         const f32x4 qh = *reinterpret_cast<const f32x4*>(e + 4 * W::WIN), isa = *reinterpret_cast<const f32x4*>(e + 5 * W::WIN);
-        f32x4 v;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f32x2 o = features2<true, false>(f32x2{wx[2 * h], wx[2 * h + 1]}, f32x2{wy[2 * h], wy[2 * h + 1]},
-                                                 f32x2{bb[2 * h], bb[2 * h + 1]}, f32x2{fr[2 * h], fr[2 * h + 1]},
-                                                 f32x2{qh[2 * h], qh[2 * h + 1]}, f32x2{isa[2 * h], isa[2 * h + 1]}, ux, uy, th);
-          v[2 * h] = o.x; v[2 * h + 1] = o.y;
-        }
+        const f32x4 v = features4_scalar(wx, wy, bb, fr, qh, isa, ux, uy, th);
         *reinterpret_cast<f32x4*>(row + W::C_IN + 4 * s4) = v;
       }
     }
@@ -341,8 +351,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
 //               record(k+1) -> record area
 //   phase B(k): multiply G2(k), G3(k) from bufB | stage into bufA: dh1(k+1), in(k+1) (re-evaluated from u(k+1))
 // Every HBM load is issued right after the registers it lands in were committed, two phases (about one chunk time) before
-// its use.  The staging of a phase is cut into seven pieces and each is issued behind one group of the phase's MFMAs: the
-// bf16 MFMA leaves the vector ALU free, so the splitting and the feature evaluation run in its shadow.
+// its use.  Waves 0..3 multiply, waves 4..7 stage (w and w + 4 share a SIMD: see the kernel).
 constexpr int KS = 32;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -384,9 +393,6 @@ __device__ __forceinline__ unsigned take_level(float& x0, float& x1) {
 }
 // four consecutive slots of one sample -> 8 bytes per level at dword offset `at` of the three images starting at `img`
 __device__ __forceinline__ void store_split4(float* lds, int img, int plane, int at, f32x4 v) {
-  // `at` opaque: otherwise the compiler keeps one precomputed address register per (item, image) pair alive across the
-  // whole chunk loop (the images lie more than a 16-bit offset apart) and spills
-  asm volatile("" : "+v"(at));
   u32x2 h, m, l;
 #ifdef NFOPP_ABL2_NO_SPLIT   /* development ablation: the three stores without the arithmetic */
   h.x = __float_as_uint(v.x); h.y = __float_as_uint(v.y); m = h; l.x = __float_as_uint(v.z); l.y = __float_as_uint(v.w);
@@ -420,13 +426,36 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// Wait states between a group of MFMAs and vector instructions that may overwrite its operand registers (see the account in
-// DESIGN.md, "MFMA operand hazards"): hipcc 7.2 pads 7 after v_mfma_f32_16x16x32_bf16, which proved too few on MI355X.
+// Wait states behind a group of MFMAs before its fragment registers are reloaded.  A precaution, not a proven need: the
+// run-to-run differences it was written against turned out to come from a packed fma with op_sel on freshly loaded LDS values
+// ("A hazard hipcc does not pad"); it costs nothing here because the multiplying waves wait at the barriers anyway.
 __device__ __forceinline__ void mfma_guard() {
 #ifndef NFOPP_NO_MFMA_GUARD
-  asm volatile("s_nop 15");
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");   // 64 wait states: four MFMA issue slots
   __builtin_amdgcn_sched_barrier(0);
 #endif
+}
+
+// Development build (make EXTRA=-DNFOPP_WG_PROFILE): waves 0 and 4 of workgroup 0 print the clock ticks they spent in their
+// work and at the barriers of the two phases.
+#ifdef NFOPP_WG_PROFILE
+#define WG_TICK(SLOT)                                              \
+  {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();  \
+    wg_ticks[SLOT] += (float)(now_ - wg_t0);                       \
+    wg_t0 = now_;                                                  \
+  }
+#else
+#define WG_TICK(SLOT)
+#endif
+
+// End of a pipeline phase.  The scheduling barrier matters: without it hipcc hoists the NEXT phase's register arithmetic (the
+// splitting of operands whose loads were issued a moment ago) above the barrier, and the s_waitcnt vmcnt(0) that goes with
+// it exposes the full HBM latency once per chunk (0.6 ms of the 1.7 ms the kernel took).
+__device__ __forceinline__ void phase_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // Two tiles that share the A operand: the two accumulation chains are independent and alternate on the matrix pipe (a chain
@@ -444,33 +473,6 @@ __device__ __forceinline__ void mfma_split_pair(const s16x8 (&a)[3], const s16x8
   c0 = mfma_bf16(a[0], b0[1], c0); c1 = mfma_bf16(a[0], b1[1], c1);
   c0 = mfma_bf16(a[0], b0[0], c0); c1 = mfma_bf16(a[0], b1[0], c1);
 }
-// One tile: the three small products go to a side accumulator, so again two chains alternate; it is added at the end.
-__device__ __forceinline__ f32x4 mfma_split_single(const s16x8 (&a)[3], const s16x8 (&b)[3], f32x4 c) {
-#ifdef NFOPP_ABL2_NO_MFMA
-  asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
-  return c;
-#endif
-  f32x4 t = {0.f, 0.f, 0.f, 0.f};
-  t = mfma_bf16(a[2], b[0], t); c = mfma_bf16(a[1], b[0], c);
-  t = mfma_bf16(a[0], b[2], t); c = mfma_bf16(a[0], b[1], c);
-  t = mfma_bf16(a[1], b[1], t); c = mfma_bf16(a[0], b[0], c);
-  return c + t;
-}
-// c += a * b for operands given as three levels (index 0 = hi): the six products above 2^-24, small ones first
-__device__ __forceinline__ f32x4 mfma_split(const s16x8 (&a)[3], const s16x8 (&b)[3], f32x4 c) {
-#ifdef NFOPP_ABL2_NO_MFMA   /* development ablation: operands are still read (kept alive), nothing multiplied */
-  asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
-  return c;
-#endif
-  c = mfma_bf16(a[2], b[0], c);
-  c = mfma_bf16(a[0], b[2], c);
-  c = mfma_bf16(a[1], b[1], c);
-  c = mfma_bf16(a[1], b[0], c);
-  c = mfma_bf16(a[0], b[1], c);
-  c = mfma_bf16(a[0], b[0], c);
-  return c;
-}
-
 template <int NKT>
 __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const WgradArgs a) {
   using L = WsLayout<NKT>;
@@ -510,327 +512,299 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
   }
   __syncthreads();   // the tables are read into registers below
 
-  // ---- staging descriptors, fixed per thread (item = one float4 of one sample of the chunk) --------------------------
-  // array X with row4 float4 per sample: item idx = tid + j * 512 -> sample q = idx / row4, float4 c = idx % row4
-  constexpr int N_H = (KS * H4 + WG_THREADS - 1) / WG_THREADS, N_W = (KS * W4 + WG_THREADS - 1) / WG_THREADS;
-  f32x4 st_dh1[N_H], st_h1[N_H], st_de[N_W], st_rec;
-  // (sample q << 8 | float4 c) of the items.  Unpacked through an opaque copy at every use: left to itself the compiler
-  // keeps a dozen derived offsets per item alive across the chunk loop and spills them.
-  int hqc[N_H], wqc[N_W];
-#pragma unroll
-  for (int j = 0; j < N_H; ++j) {
-    const int idx = tid + j * WG_THREADS;
-    const int it = idx < KS * H4 ? idx : KS * H4 - 1;   // surplus threads repeat the last item (same data, same place)
-    hqc[j] = ((it / H4) << 8) | (it % H4);
-  }
-#pragma unroll
-  for (int j = 0; j < N_W; ++j) {
-    const int idx = tid + j * WG_THREADS;
-    const int it = idx < KS * W4 ? idx : KS * W4 - 1;
-    wqc[j] = ((it / W4) << 8) | (it % W4);
-  }
-  auto unpack = [](int qc, int& q, int& c) __attribute__((always_inline)) {
-    asm volatile("" : "+v"(qc));
-    q = qc >> 8;
-    c = qc & 255;
-  };
-  const int rit = tid < KS * 3 ? tid : KS * 3 - 1, rq = rit / 3, rc = rit % 3;   // record: 3 float4 per sample
+  // ---- two kinds of waves ---------------------------------------------------------------------------------------------
+  // Waves w and w + 4 share a SIMD.  Waves 0..3 only multiply, waves 4..7 only stage: the SIMD's matrix pipe and its vector
+  // ALU each have one wave that never waits for the other kind of work.  (With every wave doing both, the partners ran the
+  // same kind of work at the same time -- MFMA groups against MFMA groups, splitting against splitting -- and the kernel
+  // took the SUM of its matrix and vector time: 1.7 ms.)  Both kinds pass the same barriers.
   const float* const ws_h1 = a.ws;
   const float* const ws_dh1 = a.ws + a.P * HS;
   const float* const ws_de = a.ws + a.P * 2 * HS;
   const float* const ws_rec = a.ws + a.P * (2 * HS + WIN);
-  // HBM loads as raw buffer loads: one resource per array and chunk (base = the chunk's first row, size = the rows that exist),
-  // so the per-item offset q * row + 16 c is a 32-bit chunk-invariant and rows past P -- and the idle items, whose offset is
-  // negative -- read as zeros without a branch
-  auto chunk_rsrc = [&](const float* base, long long chunk, int row_floats) __attribute__((always_inline)) {
-    const long long p0 = chunk * KS;
-    long long rows = a.P - p0;
-    rows = rows > KS ? KS : (rows < 0 ? 0 : rows);
-    const float* ptr = base + (rows > 0 ? p0 : 0) * row_floats;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(rows * row_floats * 4), 0x00020000);
-  };
-  auto load_h = [&](const float* base, f32x4 (&st)[N_H], long long chunk) __attribute__((always_inline)) {
-    const auto rsrc = chunk_rsrc(base, chunk, HS);
+
+  if (wave >= WG_WAVES / 2) {
+    // =============================== producers: 256 threads stage the operands ===========================================
+    constexpr int PT = WG_THREADS / 2;
+    const int pt = tid - PT;
+    // item = one float4 of one sample of the chunk; array with row4 float4 per sample: idx = pt + j * 256 -> (q, c).
+    // Surplus threads repeat the last item (same data, same place: no branches in the staging code).
+    constexpr int N_H = (KS * H4 + PT - 1) / PT, N_W = (KS * W4 + PT - 1) / PT;
+    // two register sets per array: the loads of chunk k+1 are issued at the START of the phase that commits chunk k (a whole
+    // chunk time ahead of their use, and spread over the phase instead of one burst per workgroup at its end)
+    f32x4 st_dh1[2][N_H], st_h1[2][N_H], st_de[2][N_W], st_rec[2];
+    int hqc[N_H], wqc[N_W];   // sample q << 8 | float4 c
 #pragma unroll
     for (int j = 0; j < N_H; ++j) {
-      int q, c;
-      unpack(hqc[j], q, c);
-      st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (HS * 4) + 16 * c, 0, 0));
+      const int idx = pt + j * PT, it = idx < KS * H4 ? idx : KS * H4 - 1;
+      hqc[j] = ((it / H4) << 8) | (it % H4);
     }
-  };
-  auto load_de = [&](long long chunk) __attribute__((always_inline)) {
-    const auto rsrc = chunk_rsrc(ws_de, chunk, WIN);
 #pragma unroll
     for (int j = 0; j < N_W; ++j) {
-      int q, c;
-      unpack(wqc[j], q, c);
-      st_de[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (WIN * 4) + 16 * c, 0, 0));
+      const int idx = pt + j * PT, it = idx < KS * W4 ? idx : KS * W4 - 1;
+      wqc[j] = ((it / W4) << 8) | (it % W4);
     }
-  };
-  auto load_rec = [&](long long chunk) __attribute__((always_inline)) {
-    const auto rsrc = chunk_rsrc(ws_rec, chunk, 12);
-    st_rec = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rq * 48 + 16 * rc, 0, 0));
-  };
-  auto commit_rec = [&](int parity) __attribute__((always_inline)) {
-    *reinterpret_cast<f32x4*>(lds + L::REC + parity * KS * 12 + rq * 12 + 4 * rc) = st_rec;
-  };
-  // The staging work of a phase is cut into seven pieces, one behind each group of MFMAs of the phase that multiplies out
-  // of the OTHER buffer (the bf16 MFMA leaves the vector ALU free: the pieces run in its shadow).
-  auto commit_h1 = [&](int img, const f32x4& v, int qc) __attribute__((always_inline)) {
-    int q, c;
-    unpack(qc, q, c);
-    store_split4(lds, img, L::P_H, q * L::R_H + 2 * c, v);
-  };
-  auto commit_de1 = [&](int j) __attribute__((always_inline)) {
-    int q, c;
-    unpack(wqc[j], q, c);
-    *reinterpret_cast<f32x4*>(lds + L::B_DE + q * L::RS_DE + 4 * c) = st_de[j];
-  };
-  // Rebuilt operands.  A thread's items keep their columns from chunk to chunk, so the table entries they need are loaded
-  // into registers ONCE (the LDS reads and their latency were most of the staging time at two waves per SIMD):
-  //  * dh2: item j of the hidden-side list (sample q, float4 c) -> W3a[4c .. 4c+3];
-  //  * in:  thread t < T_I owns slot quad s4 = t % W4 for the samples q = t / W4 + SP * j -> one table entry (24 floats).
-  f32x4 w3a_reg[N_H];
-#pragma unroll
-  for (int j = 0; j < N_H; ++j) w3a_reg[j] = *reinterpret_cast<const f32x4*>(lds + L::L_W3A + 4 * (hqc[j] & 255));
-  constexpr int SP = WG_THREADS / W4, T_I = SP * W4, N_I = (KS + SP - 1) / SP;
-  static_assert(N_I <= 4, "four feature-rebuild pieces per phase");
-  const int it_in = tid < T_I ? tid : tid - T_I;      // surplus threads repeat other owners' work (same data, same place:
-                                                      // no branch in the staging pieces, which interleave with MFMAs)
-  const int in_s4 = it_in % W4, in_q0 = it_in / W4;
-  f32x4 t_wx, t_wy, t_b, t_fr, t_qh, t_isa;
-  {
-    const float* e = lds + L::L_FT + 4 * in_s4;
-    t_wx = *reinterpret_cast<const f32x4*>(e); t_wy = *reinterpret_cast<const f32x4*>(e + WIN);
-    t_b = *reinterpret_cast<const f32x4*>(e + 2 * WIN); t_fr = *reinterpret_cast<const f32x4*>(e + 3 * WIN);
-    t_qh = *reinterpret_cast<const f32x4*>(e + 4 * WIN); t_isa = *reinterpret_cast<const f32x4*>(e + 5 * WIN);
-  }
-  auto rebuild_dh2 = [&](const float* rec, int j) __attribute__((always_inline)) {
-    int q, c;     // dh2 slots 4c .. 4c+3 = rho * W3a * [a2 > 0]: tile c >> 2, lane group c & 3
-    unpack(hqc[j], q, c);
-    const unsigned bits = __float_as_uint(rec[q * 12 + 8 + (c & 3)]) >> (4 * (c >> 2));
-    const float rho = rec[q * 12 + 4];
-    f32x4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = ((bits >> r) & 1u) ? w3a_reg[j][r] * rho : 0.0f;
-    store_split4(lds, L::B_DH2, L::P_H, q * L::R_H + 2 * c, v);
-  };
-  auto rebuild_in = [&](const float* rec, int j) __attribute__((always_inline)) {
-    int q = in_q0 + SP * j;   // in slots 4 s4 .. 4 s4 + 3 of sample q = features(u), pass 1's arithmetic
-    q = q < KS ? q : KS - 1;
-    asm volatile("" : "+v"(q));
-    const f32x2 ux = splat2(rec[q * 12]), uy = splat2(rec[q * 12 + 1]), th = splat2(rec[q * 12 + 3]);
-    f32x4 v;
-#ifdef NFOPP_ABL2_NO_FEAT   /* development ablation */
-    v = f32x4{ux.x, uy.x, th.x, ux.x};
-#else
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const f32x2 o = features2<true, false>(f32x2{t_wx[2 * h], t_wx[2 * h + 1]}, f32x2{t_wy[2 * h], t_wy[2 * h + 1]},
-                                             f32x2{t_b[2 * h], t_b[2 * h + 1]}, f32x2{t_fr[2 * h], t_fr[2 * h + 1]},
-                                             f32x2{t_qh[2 * h], t_qh[2 * h + 1]}, f32x2{t_isa[2 * h], t_isa[2 * h + 1]},
-                                             ux, uy, th);
-      v[2 * h] = o.x; v[2 * h + 1] = o.y;
-    }
-#endif
-    store_split4(lds, L::A_IN, L::P_IN, q * L::R_IN + 2 * in_s4, v);
-  };
-  static_assert(N_H == 2 && N_W <= 4, "the piece lists below are written for two hidden-side and up to four input-side items");
-  // piece i of phase A's staging (into bufB: h1, de, u, dh2 of the chunk whose record area is `parity`; record of the next
-  // chunk; loads of the chunk after)
-  auto stage_b = [&](auto piece_c, int parity, long long chunk) __attribute__((always_inline)) {
-    constexpr int piece = decltype(piece_c)::value;
-    const float* rec = lds + L::REC + parity * KS * 12;
-#ifdef NFOPP_ABL2_NO_STAGE   /* development ablation: loads only */
-    if constexpr (piece == 6) { load_rec(chunk + 2 * step); load_h(ws_h1, st_h1, chunk + step); load_de(chunk + step); }
-    return;
-#endif
-    if constexpr (piece == 0) { commit_rec(parity ^ 1); commit_h1(L::B_H1, st_h1[0], hqc[0]); }
-    if constexpr (piece == 1) commit_h1(L::B_H1, st_h1[1], hqc[1]);
-    if constexpr (piece == 2) { commit_de1(0); if (N_W > 1) commit_de1(1 < N_W ? 1 : 0); }
-    if constexpr (piece == 3) {
-      if (N_W > 2) commit_de1(2 < N_W ? 2 : 0);
-      if (N_W > 3) commit_de1(3 < N_W ? 3 : 0);
-      { const int t = tid & (KS * 4 - 1); lds[L::B_DE + (t >> 2) * L::RS_DE + WIN + (t & 3)] = rec[(t >> 2) * 12 + (t & 3)]; }
-    }
-    if constexpr (piece == 4) rebuild_dh2(rec, 0);
-    if constexpr (piece == 5) rebuild_dh2(rec, 1);
-#ifndef NFOPP_ABL2_NO_LOADS
-    if constexpr (piece == 6) { load_rec(chunk + 2 * step); load_h(ws_h1, st_h1, chunk + step); load_de(chunk + step); }
-#endif
-  };
-  // piece i of phase B's staging (into bufA: dh1 and in = features(u) of the NEXT chunk, record area `parity`)
-  auto stage_a = [&](auto piece_c, int parity, long long chunk) __attribute__((always_inline)) {
-    constexpr int piece = decltype(piece_c)::value;
-    const float* rec = lds + L::REC + parity * KS * 12;
-#ifdef NFOPP_ABL2_NO_STAGE
-    if constexpr (piece == 6) load_h(ws_dh1, st_dh1, chunk + 2 * step);
-    return;
-#endif
-    if constexpr (piece == 0) commit_h1(L::A_DH1, st_dh1[0], hqc[0]);
-    if constexpr (piece == 1) commit_h1(L::A_DH1, st_dh1[1], hqc[1]);
-    if constexpr (piece >= 2 && piece <= 5) { if (piece - 2 < N_I) rebuild_in(rec, piece - 2); }
-#ifndef NFOPP_ABL2_NO_LOADS
-    if constexpr (piece == 6) load_h(ws_dh1, st_dh1, chunk + 2 * step);
-#endif
-  };
-
-  // ---- this wave's output tiles -------------------------------------------------------------------------------------
-  // G1 (7 x NKT tiles, dh1^T in): column blocks 2w, 2w+1 for waves 0..5, 12 + (w - 6) for waves 6, 7; all 7 row blocks.
-  // G2 (7 x 7, dh2^T h1): waves 6, 7 take column blocks {0,1} / {2,3}; waves 0..5 column block 4 + (w >> 1), row blocks
-  //   0..3 (even w) or 4..6 (odd w).   G3 (NKT x 1, de^T u, fp32): row blocks w, w + 6, w + 12 of waves 0..5.
-  // 21 accumulator tiles either way: "wide" waves 0..5 = 14 G1 + 4 G2 + 3 G3, waves 6, 7 = 7 G1 + 14 G2; the two kinds run
-  // two instantiations of the same body (static accumulator indices).
-  // lane part of every transposing read: row (set of this lane group) + q, dwords 2p of the block's 8
-  const int grp = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, i16 = lane & 15;
-  const int row0 = 16 * (grp >> 1) + 4 * (grp & 1) + qq;
-  const int lane_h = row0 * L::R_H + 2 * pp, lane_in = row0 * L::R_IN + 2 * pp;
-
-  auto body = [&](auto wide_c) __attribute__((always_inline)) {
-    constexpr bool WIDE = decltype(wide_c)::value;
-    constexpr int NC1 = WIDE ? 2 : 1, NC2 = WIDE ? 1 : 2, NR2 = WIDE ? 4 : 7;
-    const int g1_cb = WIDE ? 2 * wave : 12 + (wave - 6);
-    const int g2_cb = WIDE ? 4 + (wave >> 1) : 2 * (wave - 6);
-    const int g2_rb0 = WIDE ? 4 * (wave & 1) : 0;
-    // one base register per image, with this wave's column / first row block folded in: every read offset below is a
-    // compile-time constant under 64 KB and goes into the instruction's offset field
-    const float* const bA_dh1 = lds + L::A_DH1 + lane_h;
-    const float* const bA_in = lds + L::A_IN + lane_in + 8 * g1_cb;
-    const float* const bB_dh2 = lds + L::B_DH2 + lane_h + 8 * g2_rb0;
-    const float* const bB_h1 = lds + L::B_H1 + lane_h + 8 * g2_cb;
-    f32x4 acc1[NC1][7], acc2[NC2][NR2], acc3[3];
-#pragma unroll
-    for (int c = 0; c < NC1; ++c)
-#pragma unroll
-      for (int r = 0; r < 7; ++r) acc1[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < NC2; ++c)
-#pragma unroll
-      for (int r = 0; r < NR2; ++r) acc2[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // hook(i), i = 0..6: one piece of the other buffer's staging, issued as a block behind the MFMAs of step i.  (Dealing the
-    // piece's instructions out BETWEEN the MFMAs with sched_group_barrier gained 2 % and made the result differ from run to
-    // run on the GPU -- a hazard between the 8-pass MFMA and neighbouring vector instructions that hipcc 7.2 does not pad;
-    // the block form is bitwise reproducible, tests/test_gpu_benchmr.py checks it at full size.)
-    auto mul_g1 = [&](auto&& hook) __attribute__((always_inline)) {
-      s16x8 bf[NC1][3];
-#pragma unroll
-      for (int c = 0; c < NC1; ++c)
-#pragma unroll
-        for (int lv = 0; lv < 3; ++lv) bf[c][lv] = read_frag<L::R_IN>(bA_in, lv * L::P_IN + 8 * c);
-      s16x8 af[3], an[3];
-#pragma unroll
-      for (int lv = 0; lv < 3; ++lv) af[lv] = read_frag<L::R_H>(bA_dh1, lv * L::P_H);
-      static_for<0, 7>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        if constexpr (r + 1 < 7)
-#pragma unroll
-          for (int lv = 0; lv < 3; ++lv) an[lv] = read_frag<L::R_H>(bA_dh1, lv * L::P_H + 8 * (r + 1));
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NC1 == 2) mfma_split_pair(af, bf[0], bf[1], acc1[0][r], acc1[1][r]);
-        else acc1[0][r] = mfma_split_single(af, bf[0], acc1[0][r]);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_guard();
-        hook(rc);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int lv = 0; lv < 3; ++lv) af[lv] = an[lv];
-      });
+    auto unpack = [](int qc, int& q, int& c) __attribute__((always_inline)) {
+      q = qc >> 8;
+      c = qc & 255;
     };
-    // G2 (+ G3 on the wide waves): 7 steps as well -- wide: 4 row blocks of G2, then 3 tiles of G3; narrow: 7 row blocks
-    auto mul_g23 = [&](auto&& hook) __attribute__((always_inline)) {
-      s16x8 bf[NC2][3];
-#pragma unroll
-      for (int c = 0; c < NC2; ++c)
-#pragma unroll
-        for (int lv = 0; lv < 3; ++lv) bf[c][lv] = read_frag<L::R_H>(bB_h1, lv * L::P_H + 8 * c);
-      // odd wide waves: row blocks 4, 5, 6 and an idle slot that reads past block 6 into the next sample row (in the image,
-      // never stored)
-      s16x8 af[3], an[3];
-#pragma unroll
-      for (int lv = 0; lv < 3; ++lv) af[lv] = read_frag<L::R_H>(bB_dh2, lv * L::P_H);
-      const float* rowk = lds + L::B_DE + grp * L::RS_DE + i16;
-      static_for<0, 7>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        if constexpr (r < NR2) {
-          if constexpr (r + 1 < NR2)
-#pragma unroll
-            for (int lv = 0; lv < 3; ++lv) an[lv] = read_frag<L::R_H>(bB_dh2, lv * L::P_H + 8 * (r + 1));
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (NC2 == 2) mfma_split_pair(af, bf[0], bf[1], acc2[0][r], acc2[1][r]);
-          else acc2[0][r] = mfma_split_single(af, bf[0], acc2[0][r]);
-          __builtin_amdgcn_sched_barrier(0);
-          mfma_guard();
-          hook(rc);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int lv = 0; lv < 3; ++lv) af[lv] = an[lv];
-        } else {                         // wide waves, steps 4..6: G3 tile j = r - 4 (fp32 MFMA, K = 4 samples per step)
-          constexpr int j = r - NR2;
-          const int rb = wave + 6 * j;
-          if (rb < NKT) {
-#pragma unroll
-            for (int s = 0; s < KS / 4; ++s)
-              acc3[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rowk[4 * s * L::RS_DE + 16 * rb], rowk[4 * s * L::RS_DE + WIN],
-                                                             acc3[j], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          mfma_guard();
-          hook(rc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
+    const int rit = pt < KS * 3 ? pt : KS * 3 - 1, rq = rit / 3, rc = rit % 3;   // record: 3 float4 per sample
+    // HBM loads as raw buffer loads: one resource per array and chunk (base = the chunk's first row, size = the rows that
+    // exist), so the per-item offset q * row + 16 c is a 32-bit chunk-invariant and rows past P read as zeros without a branch
+    auto chunk_rsrc = [&](const float* base, long long chunk, int row_floats) __attribute__((always_inline)) {
+      const long long p0 = chunk * KS;
+      long long rows = a.P - p0;
+      rows = rows > KS ? KS : (rows < 0 ? 0 : rows);
+      const float* ptr = base + (rows > 0 ? p0 : 0) * row_floats;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(rows * row_floats * 4), 0x00020000);
     };
-
-    // ---- pipeline ----------------------------------------------------------------------------------------------------
-    // prologue: record(c0) and bufA(c0) in place, record(c0 + step), dh1(c0 + step) and h1 / de (c0) in registers
+    auto load_h = [&](const float* base, f32x4 (&st)[N_H], long long chunk) __attribute__((always_inline)) {
+      const auto rsrc = chunk_rsrc(base, chunk, HS);
+#pragma unroll
+      for (int j = 0; j < N_H; ++j) {
+        int q, c;
+        unpack(hqc[j], q, c);
+        st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (HS * 4) + 16 * c, 0, 0));
+      }
+    };
+    auto load_de = [&](f32x4 (&st)[N_W], long long chunk) __attribute__((always_inline)) {
+      const auto rsrc = chunk_rsrc(ws_de, chunk, WIN);
+#pragma unroll
+      for (int j = 0; j < N_W; ++j) {
+        int q, c;
+        unpack(wqc[j], q, c);
+        st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (WIN * 4) + 16 * c, 0, 0));
+      }
+    };
+    auto load_rec = [&](f32x4& st, long long chunk) __attribute__((always_inline)) {
+      const auto rsrc = chunk_rsrc(ws_rec, chunk, 12);
+      st = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rq * 48 + 16 * rc, 0, 0));
+    };
+    auto commit_rec = [&](const f32x4& st, int parity) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x4*>(lds + L::REC + parity * KS * 12 + rq * 12 + 4 * rc) = st;
+    };
+    auto commit_h = [&](int img, const f32x4 (&st)[N_H]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < N_H; ++j) {
+        int q, c;
+        unpack(hqc[j], q, c);
+        store_split4(lds, img, L::P_H, q * L::R_H + 2 * c, st[j]);
+      }
+    };
+    // Rebuilt operands.  A thread's items keep their columns from chunk to chunk, so the table entries they need sit in
+    // registers:  dh2: item j of the hidden-side list (sample q, float4 c) -> W3a[4c .. 4c+3];
+    //             in:  thread t < T_I owns slot quad s4 = t % W4 for the samples q = t / W4 + SP * j (one 24-float entry).
+    f32x4 w3a_reg[N_H];
+#pragma unroll
+    for (int j = 0; j < N_H; ++j) w3a_reg[j] = *reinterpret_cast<const f32x4*>(lds + L::L_W3A + 4 * (hqc[j] & 255));
+    constexpr int SP = PT / W4, T_I = SP * W4, N_I = (KS + SP - 1) / SP;
+    const int it_in = pt < T_I ? pt : pt - T_I;       // surplus threads repeat other owners' work
+    const int in_s4 = it_in % W4, in_q0 = it_in / W4;
+    f32x4 t_wx, t_wy, t_b, t_fr, t_qh, t_isa;
+    {
+      const float* e = lds + L::L_FT + 4 * in_s4;
+      t_wx = *reinterpret_cast<const f32x4*>(e); t_wy = *reinterpret_cast<const f32x4*>(e + WIN);
+      t_b = *reinterpret_cast<const f32x4*>(e + 2 * WIN); t_fr = *reinterpret_cast<const f32x4*>(e + 3 * WIN);
+      t_qh = *reinterpret_cast<const f32x4*>(e + 4 * WIN); t_isa = *reinterpret_cast<const f32x4*>(e + 5 * WIN);
+    }
+#ifdef NFOPP_WG_PROFILE
+    float wg_ticks[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned long long wg_t0 = __builtin_readcyclecounter();
+#endif
+    // phase A(k)'s staging (register set s = record area of chunk k), into bufB: h1, de, u, dh2 of chunk k; the record of chunk
+    // k+1 -> area s^1.  Loads first: h1, de of chunk k+1 and the record of chunk k+2 into the other set.
+    auto stage_b = [&](auto set_c, long long chunk) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      load_h(ws_h1, st_h1[S ^ 1], chunk + step);
+      load_de(st_de[S ^ 1], chunk + step);
+      load_rec(st_rec[S ^ 1], chunk + 2 * step);
+      WG_TICK(4)
+      const float* rec = lds + L::REC + S * KS * 12;
+      commit_rec(st_rec[S], S ^ 1);
+      commit_h(L::B_H1, st_h1[S]);
+      WG_TICK(5)
+#pragma unroll
+      for (int j = 0; j < N_W; ++j) {
+        int q, c;
+        unpack(wqc[j], q, c);
+        *reinterpret_cast<f32x4*>(lds + L::B_DE + q * L::RS_DE + 4 * c) = st_de[S][j];
+      }
+      { const int t = pt & (KS * 4 - 1); lds[L::B_DE + (t >> 2) * L::RS_DE + WIN + (t & 3)] = rec[(t >> 2) * 12 + (t & 3)]; }
+      WG_TICK(6)
+#pragma unroll
+      for (int j = 0; j < N_H; ++j) {   // dh2 slots 4c .. 4c+3 = rho * W3a * [a2 > 0]: tile c >> 2, lane group c & 3
+        int q, c;
+        unpack(hqc[j], q, c);
+        const unsigned bits = __float_as_uint(rec[q * 12 + 8 + (c & 3)]) >> (4 * (c >> 2));
+        const float rho = rec[q * 12 + 4];
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((bits >> r) & 1u) ? w3a_reg[j][r] * rho : 0.0f;
+        store_split4(lds, L::B_DH2, L::P_H, q * L::R_H + 2 * c, v);
+      }
+    };
+    // phase B(k)'s staging, into bufA: dh1 (set s) and in = features(u) of chunk k+1 (record area s^1); first the load of
+    // dh1 of chunk k+2 into the other set
+    auto stage_a = [&](auto set_c, long long chunk) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      load_h(ws_dh1, st_dh1[S ^ 1], chunk + 2 * step);
+      WG_TICK(8)
+      const float* rec = lds + L::REC + (S ^ 1) * KS * 12;
+      commit_h(L::A_DH1, st_dh1[S]);
+      WG_TICK(9)
+#pragma unroll
+      for (int j = 0; j < N_I; ++j) {
+        int q = in_q0 + SP * j;   // in slots 4 s4 .. 4 s4 + 3 of sample q = features(u), pass 1's arithmetic
+        q = q < KS ? q : KS - 1;
+        const float ux = rec[q * 12], uy = rec[q * 12 + 1], th = rec[q * 12 + 3];
+        const f32x4 v = features4_scalar(t_wx, t_wy, t_b, t_fr, t_qh, t_isa, ux, uy, th);
+        store_split4(lds, L::A_IN, L::P_IN, q * L::R_IN + 2 * in_s4, v);
+      }
+    };
+    // prologue: record(c0) -> area 0 and bufA(c0) in place; record(c0 + step), h1 / de (c0) and dh1(c0 + step) in set 0
     if (c0 < n_chunks) {
-      load_rec(c0);
-      load_h(ws_dh1, st_dh1, c0);
-      commit_rec(0);
-      load_rec(c0 + step);                      // past P: zeros
-      load_h(ws_h1, st_h1, c0);
-      load_de(c0);
-      __syncthreads();
-      static_for<0, 6>([&](auto pc) __attribute__((always_inline)) { stage_a(pc, 0, c0); });
-      load_h(ws_dh1, st_dh1, c0 + step);
-      __syncthreads();
+      load_rec(st_rec[1], c0);
+      load_h(ws_dh1, st_dh1[1], c0);
+      load_rec(st_rec[0], c0 + step);           // past P: zeros
+      load_h(ws_h1, st_h1[0], c0);
+      load_de(st_de[0], c0);
+      commit_rec(st_rec[1], 0);
+      phase_barrier();
+      // = stage_a of a chunk "c0 - step" whose set is 1: stages dh1(c0) from set 1 with record area 0, loads dh1(c0 + step) -> set 0
+      stage_a(std::integral_constant<int, 1>{}, c0 - step);
+      phase_barrier();
     }
-    int parity = 0;                             // record area of the chunk being multiplied
-    for (long long chunk = c0; chunk < n_chunks; chunk += step) {
-      mul_g1([&](auto pc) __attribute__((always_inline)) { stage_b(pc, parity, chunk); });         // phase A
-      __syncthreads();
-      mul_g23([&](auto pc) __attribute__((always_inline)) { stage_a(pc, parity ^ 1, chunk); });    // phase B
-      __syncthreads();
-      parity ^= 1;
-    }
-
-    // ---- per-workgroup partial tiles (tile numbering and element order of the fp32 kernel) ------------------------------
-    auto put = [&](int T, const f32x4& v) __attribute__((always_inline)) {
-      float* o = a.partial + ((long long)blockIdx.x * L::NTILES + T) * 256 + lane;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[64 * r] = v[r];
+    auto one_chunk = [&](auto set_c, long long chunk) __attribute__((always_inline)) {
+      stage_b(set_c, chunk);                    // phase A
+      WG_TICK(0)
+      phase_barrier();
+      WG_TICK(1)
+      stage_a(set_c, chunk);                    // phase B
+      WG_TICK(2)
+      phase_barrier();
+      WG_TICK(3)
     };
-#pragma unroll
-    for (int c = 0; c < NC1; ++c)
-      if (g1_cb + c < NKT)
-#pragma unroll
-        for (int r = 0; r < 7; ++r) put(r * NKT + g1_cb + c, acc1[c][r]);
-#pragma unroll
-    for (int c = 0; c < NC2; ++c)
-#pragma unroll
-      for (int r = 0; r < NR2; ++r)
-        if (g2_rb0 + r < 7) put(7 * NKT + (g2_rb0 + r) * 7 + g2_cb + c, acc2[c][r]);
-    if constexpr (WIDE) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (wave + 6 * j < NKT) put(7 * NKT + 49 + wave + 6 * j, acc3[j]);
+    for (long long chunk = c0; chunk < n_chunks; chunk += 2 * step) {
+      one_chunk(std::integral_constant<int, 0>{}, chunk);
+      if (chunk + step < n_chunks) one_chunk(std::integral_constant<int, 1>{}, chunk + step);
     }
+#ifdef NFOPP_WG_PROFILE
+    if (blockIdx.x == 0 && tid == WG_THREADS / 2)
+      printf("producer wave 4: phase A: loads %.0f, h1 %.0f, de + u %.0f, dh2 %.0f | barrier %.0f | phase B: load %.0f, dh1 %.0f, in %.0f "
+             "| barrier %.0f ticks\n", wg_ticks[4], wg_ticks[5], wg_ticks[6], wg_ticks[0], wg_ticks[1], wg_ticks[8], wg_ticks[9],
+             wg_ticks[2], wg_ticks[3]);
+#endif
+    return;
+  }
+
+  // ================================= consumers: waves 0..3 multiply =======================================================
+  // G1 (7 x NKT tiles, dh1^T in): wave w owns the column blocks w, w + 4, w + 8, w + 12, all 7 row blocks each (a column block
+  //   past NKT is multiplied on whatever the image holds there and never stored: 28 tiles for every wave).
+  // G2 (7 x 7, dh2^T h1): w2 -> column blocks {2, 3}, w3 -> {4, 5}, w0 -> {0, 6}, w1 -> {1, 6}; block 6 is computed by both w0
+  //   and w1 and stored by rows (w0: row blocks 0..3, w1: 4..6).   G3 (NKT x 1, de^T u, fp32): row blocks w, w+4, w+8, w+12.
+  const int grp = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, i16 = lane & 15;
+  const int row0 = 16 * (grp >> 1) + 4 * (grp & 1) + qq;   // lane part of every transposing read: sample row, dwords 2p
+  const int lane_h = row0 * L::R_H + 2 * pp, lane_in = row0 * L::R_IN + 2 * pp;
+  const int g2_cb0 = wave < 2 ? wave : 2 * wave - 2, g2_cb1 = wave < 2 ? 6 : 2 * wave - 1;
+  // one base register per image, with this wave's first column block folded in: every read offset below is a compile-time
+  // constant under 64 KB and goes into the instruction's offset field
+  const float* const bA_dh1 = lds + L::A_DH1 + lane_h;
+  const float* const bA_in = lds + L::A_IN + lane_in + 8 * wave;          // + 32 dwords per further column block
+  const float* const bB_dh2 = lds + L::B_DH2 + lane_h;
+  const float* const bB_h1a = lds + L::B_H1 + lane_h + 8 * g2_cb0;
+  const float* const bB_h1b = lds + L::B_H1 + lane_h + 8 * g2_cb1;
+  const float* const rowk = lds + L::B_DE + grp * L::RS_DE + i16;
+  f32x4 acc1[4][7], acc2[2][7], acc3[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) acc1[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) acc2[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // 7 row blocks against one pair of column blocks; the A fragments ping-pong between two register sets (no copies)
+  auto mul_pair = [&](const float* a_base, const float* b0_base, const float* b1_base, int b_plane, auto r_in_c,
+                      f32x4 (&c0)[7], f32x4 (&c1)[7]) __attribute__((always_inline)) {
+    constexpr int RB = decltype(r_in_c)::value;   // row length of the B image
+    s16x8 bf0[3], bf1[3], af[2][3];
+    mfma_guard();   // the fragment registers below were operands of the MFMAs just issued
+#pragma unroll
+    for (int lv = 0; lv < 3; ++lv) {
+      bf0[lv] = read_frag<RB>(b0_base, lv * b_plane);
+      bf1[lv] = read_frag<RB>(b1_base, lv * b_plane);
+      af[0][lv] = read_frag<L::R_H>(a_base, lv * L::P_H);
+    }
+    static_for<0, 7>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      if constexpr (r + 1 < 7) {
+        if constexpr (r > 0) mfma_guard();   // set (r + 1) & 1 was read by step r - 1's MFMAs, issued just before
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) af[(r + 1) & 1][lv] = read_frag<L::R_H>(a_base, lv * L::P_H + 8 * (r + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_split_pair(af[r & 1], bf0, bf1, c0[r], c1[r]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
-  if (wave < 6) body(std::true_type{});
-  else body(std::false_type{});
+  if (c0 < n_chunks) {
+    phase_barrier();
+    phase_barrier();
+  }
+#ifdef NFOPP_WG_PROFILE
+  float wg_ticks[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned long long wg_t0 = __builtin_readcyclecounter();
+#endif
+  for (long long chunk = c0; chunk < n_chunks; chunk += step) {
+    // phase A: G1 out of bufA
+    mul_pair(bA_dh1, bA_in, bA_in + 32, L::P_IN, std::integral_constant<int, L::R_IN>{}, acc1[0], acc1[1]);
+    mul_pair(bA_dh1, bA_in + 64, bA_in + 96, L::P_IN, std::integral_constant<int, L::R_IN>{}, acc1[2], acc1[3]);
+    WG_TICK(0)
+    phase_barrier();
+    WG_TICK(1)
+    // phase B: G2 and G3 out of bufB
+    mul_pair(bB_dh2, bB_h1a, bB_h1b, L::P_H, std::integral_constant<int, L::R_H>{}, acc2[0], acc2[1]);
+#pragma unroll
+    for (int s = 0; s < KS / 4; ++s) {          // G3: four independent fp32 chains, k-step outer
+      const float bu = rowk[4 * s * L::RS_DE + WIN];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rb = wave + 4 * j < NKT ? wave + 4 * j : NKT - 1;   // idle slot: repeats the last row block, never stored
+        acc3[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rowk[4 * s * L::RS_DE + 16 * rb], bu, acc3[j], 0, 0, 0);
+      }
+    }
+    WG_TICK(2)
+    phase_barrier();
+    WG_TICK(3)
+  }
+#ifdef NFOPP_WG_PROFILE
+  if (blockIdx.x == 0 && tid == 0)
+    printf("consumer wave 0: G1 %.0f | barrier %.0f | G2+G3 %.0f | barrier %.0f ticks\n", wg_ticks[0], wg_ticks[1], wg_ticks[2],
+           wg_ticks[3]);
+#endif
+
+  // ---- per-workgroup partial tiles (tile numbering and element order of the fp32 kernel) ---------------------------------
+  auto put = [&](int T, const f32x4& v) __attribute__((always_inline)) {
+    float* o = a.partial + ((long long)blockIdx.x * L::NTILES + T) * 256 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[64 * r] = v[r];
+  };
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (wave + 4 * c < NKT)
+#pragma unroll
+      for (int r = 0; r < 7; ++r) put(r * NKT + wave + 4 * c, acc1[c][r]);
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    put(7 * NKT + r * 7 + g2_cb0, acc2[0][r]);
+    const bool mine = wave >= 2 || (wave == 0 ? r < 4 : r >= 4);   // column block 6 is split by rows between waves 0 and 1
+    if (mine) put(7 * NKT + r * 7 + g2_cb1, acc2[1][r]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (wave + 4 * j < NKT) put(7 * NKT + 49 + wave + 4 * j, acc3[j]);
 }
 
 // reduced[e] = sum over workgroups of partial[wg][e], fixed order

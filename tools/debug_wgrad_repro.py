@@ -14,6 +14,11 @@ if os.environ.get("NFOPP_DEV_LIB"):
     _lib.LIB_PATH = os.environ["NFOPP_DEV_LIB"]
 torch.manual_seed(0)
 onf = nfopp.ONF(0.0, 10.0, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to("cuda")
+if os.environ.get("GOLDEN_FIELD"):      # the fitted sigma = 10 field of the bench-mr fixtures instead of a random one
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+    import gpu_common as gc
+    z = np.load(os.path.join(ROOT, "tests", "golden", "traj_benchmr_n512.npz"))
+    onf, _ = gc.make_onf(z["cfg"], z["params"])
 g = onf.geometry() if hasattr(onf, "geometry") else None
 fit = nfopp.OnfFitter(onf, 2e-2, (0.9, 0.9), distributed=False)
 RUNS = int(os.environ.get("RUNS", "10"))
