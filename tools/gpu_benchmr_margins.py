@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "pytorch-motion-
     sys.path.insert(0, p)
 import gpu_common as gc  # noqa: E402
 import nfopp  # noqa: E402
+from nfopp import _lib  # noqa: E402
+
+if os.environ.get("NFOPP_DEV_LIB"):      # margins of a development build
+    _lib.LIB_PATH = os.environ["NFOPP_DEV_LIB"]
 from conftest import load_golden  # noqa: E402
 from oracle import nfopp_oracle as orc  # noqa: E402
 
