@@ -339,3 +339,29 @@ def test_fit_gradient_repeats_bit_for_bit():
             rows, cols = sorted(set((w1 // 220).tolist())), sorted(set((w1 % 220).tolist()))
             raise AssertionError("repeat %d differs in %d elements %s, max |d| %.3e; pass 1 factors identical: %s; W1 rows %s "
                                  "cols %s" % (k, len(idx), per_block, float(d.max()), same_factors, rows, cols))
+
+
+def test_fused_onf_kernel_repeats_bit_for_bit():
+    """K1 at the benchmark size (4096 x 256: 1 044 480 collision samples), 20 repeats on the same trajectories and the same
+    injected t, in trajectory mode and in forward-only pose mode: bit for bit the same every time.  Companion of
+    test_fit_gradient_repeats_bit_for_bit -- a timing-dependent hazard shows up as a repeat that differs, not as a wrong mean."""
+    z = load_golden("traj_benchmr_n256.npz")
+    onf, cfg = gc.make_onf(z["cfg"], z["params"])
+    hp = orc.Hyper.from_npz(z)
+    B, N = 4096, 256
+    rng = np.random.default_rng(9)
+    traj = (rng.random((B, N, 3)) * [100.0, 100.0, 6.0] - [0.0, 0.0, 3.0]).astype(F32)
+    t = rng.random((B, N - 1)).astype(F32)
+    zeros = np.zeros((B, 3), F32)
+    s = dict(traj=traj, start=zeros, goal=zeros, lam=np.zeros((B, N + 1), F32), cm=np.zeros((B, N), F32),
+             adam_m=np.zeros((B, N, 3), F32), adam_v=np.zeros((B, N, 3), F32), adam_step=0)
+    eng = gc.engine_from_state(onf, s, hp)
+    eng.collision_eval(t)
+    first = eng.onf_out.clone()
+    poses = torch.tensor(traj.reshape(-1, 3), device="cuda")
+    first_logits = onf(poses).clone()
+    assert torch.isfinite(first).all() and torch.isfinite(first_logits).all()
+    for k in range(20):
+        eng.collision_eval(t)
+        assert torch.equal(eng.onf_out, first), k
+        assert torch.equal(onf(poses), first_logits), k
