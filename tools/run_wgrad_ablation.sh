@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool: kernel time of onf_wgrad_split_kernel in the ablation builds (make ... EXTRA=-DNFOPP_ABL2_<x>  OUT=build/abl2_<x>)
 export TMPDIR=/tmp; R=$PWD; mkdir -p gpurun_out
-for v in "" NO_MFMA NO_SPLIT NO_FEAT NO_FRAGREAD; do
+for v in "" NO_MFMA NO_SPLIT NO_FRAGREAD; do
   lib=$R/pytorch-motion-planner_amd/nfopp/lib/libnfopp_hip.so
   [ -n "$v" ] && lib=$R/build/abl2_$v/libnfopp_hip.so
   [ -f $lib ] || continue
