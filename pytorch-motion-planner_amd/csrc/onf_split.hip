@@ -198,7 +198,6 @@ template <int NKT, int NT, int MODE>
 __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const OnfKernelArgs a, const u32x4* __restrict__ blob) {
   constexpr bool FWD_ONLY = MODE == 2;
   constexpr bool TRAIN = MODE == 1;
-  static_assert(!TRAIN || NT == 1, "the training pass runs one point tile per wave");
   using L = Lds<NKT>;
   using B = Blob<NKT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -871,6 +870,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
       // tile mt's steps.  92 work items per tile: evaluation e = w / 11 (feature row r = e >> 1 of point tile e & 1),
       // step w % 11; four to a slot.  Same arithmetic and order as l1t_tile's epilogue.
       f32x4 acc_prev[NT], acc_cur[NT];
+      f32x4 de_prev[NT];   // TRAIN: de of the tile whose epilogue is in flight
       float d_arg = 0.f, d_j = 0.f, d_r = 0.f, d_t = 0.f, d_de = 0.f;
       // compact entry (wx, wy, b, qh) of feature row r, ping-pong on r & 1.  Kept as scalars: with the entry held as one
       // f32x4, hipcc 7.2's SLP pass fused the two tiles' gy updates into v_pk_fma_f32 ... op_sel:[0,1,0] and the low lane
@@ -898,15 +898,24 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
         if (u == 6) d_t = fmaf(d_r, 0.159154943f, dq[b]);
         if (u == 7) d_t = __builtin_amdgcn_sinf(d_t);
         if (u == 8) d_de = acc_prev[tl][r] * d_t;
-        if (u == 9) gx[tl] = fmaf(d_de, dwx[b], gx[tl]);
-        if (u == 10) gy[tl] = fmaf(d_de, dwy[b], gy[tl]);
+        if constexpr (TRAIN) {   // the fit needs de itself (stored per tile below), not d logit / d pose
+          if (u == 9) de_prev[tl][r] = d_de;
+        } else {
+          if (u == 9) gx[tl] = fmaf(d_de, dwx[b], gx[tl]);
+          if (u == 10) gy[tl] = fmaf(d_de, dwy[b], gy[tl]);
+        }
+      };
+      auto store_de = [&](int mt, const f32x4 (&de)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+          if (pidx[tl] < a.n_points) *reinterpret_cast<f32x4*>(a.ws_de + pidx[tl] * WIN + 16 * mt + 4 * g) = de[tl];
       };
       auto l1t_steps = [&](auto hook_c, int mt, f32x4 (&acc)[NT]) __attribute__((always_inline)) {
         constexpr bool HOOK = decltype(hook_c)::value;
         const int fbase = base_p(mt) + colP;
         const f32x4 w3b = *reinterpret_cast<const f32x4*>(lds + L::W3B + fbase);
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc[tl] = w3b;
+        for (int tl = 0; tl < NT; ++tl) acc[tl] = TRAIN ? w3b * rho[tl] : w3b;
         const int lo_step = B::L1T + mt * B::HKB;
         if (HOOK) { pm_base = base_p(mt - 1) + colP; dtable_load(0); }
 #pragma unroll
@@ -955,10 +964,15 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
           const f32x2 wx = {e0.x, e0.y}, wy = {e0.z, e0.w}, bb = {e1.x, e1.y}, fr = {e1.z, e1.w};
           const f32x2 cof = features2<ANG, true>(wx, wy, bb, fr, qh, splat2(isa4[r]), ux2, uy2, th2);
           const f32x2 de = f32x2{acc[0][r], acc[NT - 1][r]} * cof;
-          gx2 = fma2(de, wx, gx2);
-          gy2 = fma2(de, wy, gy2);
-          if (ANG) gt2 = fma2(de, fr, gt2);
+          if constexpr (TRAIN) {
+            de_prev[0][r] = de.x; de_prev[NT - 1][r] = de.y;
+          } else {
+            gx2 = fma2(de, wx, gx2);
+            gy2 = fma2(de, wy, gy2);
+            if (ANG) gt2 = fma2(de, fr, gt2);
+          }
         }
+        if constexpr (TRAIN) store_de(mt, de_prev);
         gx[0] = gx2.x; gx[NT - 1] = gx2.y; gy[0] = gy2.x; gy[NT - 1] = gy2.y; gt[0] = gt2.x; gt[NT - 1] = gt2.y;
       };
       // tiles 0 .. first_angle_kt-1 carry no angle features: their epilogues hide behind the next tile's steps
@@ -967,6 +981,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
 #pragma unroll 1
       for (int mt = 1; mt <= plain_tiles; ++mt) {
         l1t_steps(std::true_type{}, mt, acc_cur);
+        if constexpr (TRAIN) store_de(mt - 1, de_prev);   // the epilogue of tile mt - 1 ran behind tile mt's steps
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc_prev[tl] = acc_cur[tl];
       }
@@ -1122,11 +1137,16 @@ static int launch_split_mode(const OnfKernelArgs& a, hipStream_t stream) {
   }
 }
 
-// training pass on the split path (one point tile per wave)
+// training pass on the split path: two point tiles per wave on the shadow steps for F = 200..224 (spills 344 B of registers and
+// is still 9 % faster than one tile per wave), one tile per wave otherwise
 int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out) {
   const int nkt = (a.geom.fin + 15) / 16;
   switch (nkt) {
+#ifdef NFOPP_TRAIN_NT1   /* development A/B: one point tile per wave, as before round 2's last change */
     case 14: return launch_split_t<14, 1, 1>(a, stream, grid_out);
+#else
+    case 14: return launch_split_t<14, 2, 1>(a, stream, grid_out);
+#endif
     case 13: return launch_split_t<13, 1, 1>(a, stream, grid_out);
     case 8: return launch_split_t<8, 1, 1>(a, stream, grid_out);
     case 7: return launch_split_t<7, 1, 1>(a, stream, grid_out);
