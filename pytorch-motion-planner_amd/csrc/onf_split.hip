@@ -1142,10 +1142,14 @@ static int launch_split_mode(const OnfKernelArgs& a, hipStream_t stream) {
 int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out) {
   const int nkt = (a.geom.fin + 15) / 16;
   switch (nkt) {
-#ifdef NFOPP_TRAIN_NT1   /* development A/B: one point tile per wave, as before round 2's last change */
+#ifdef NFOPP_TRAIN_NT1   /* development A/B: one point tile per wave at any size */
     case 14: return launch_split_t<14, 1, 1>(a, stream, grid_out);
 #else
-    case 14: return launch_split_t<14, 2, 1>(a, stream, grid_out);
+    // two tiles per wave once every CU gets a full workgroup of them (as the evaluation kernel decides); smaller fits fill more
+    // CUs with one tile per wave (4096 samples: 57 vs 85 us)
+    case 14:
+      return a.n_points < (long long)query_cus() * WAVES * 16 * 2 ? launch_split_t<14, 1, 1>(a, stream, grid_out)
+                                                                   : launch_split_t<14, 2, 1>(a, stream, grid_out);
 #endif
     case 13: return launch_split_t<13, 1, 1>(a, stream, grid_out);
     case 8: return launch_split_t<8, 1, 1>(a, stream, grid_out);

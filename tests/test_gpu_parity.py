@@ -321,7 +321,7 @@ def test_onf_training_paths_vs_golden(path):
     assert max_abs(g[:-2], z["grad"]) < 3e-6 * max(1.0, float(np.abs(z["grad"]).max()))
 
 
-@pytest.mark.parametrize("tag,P", [("a", 5000), ("b", 3001), ("c", 2500)])
+@pytest.mark.parametrize("tag,P", [("a", 5000), ("b", 3001), ("c", 2500), ("a", 70001)])   # 70001: two point tiles per wave
 def test_onf_training_mfma_path_vs_oracle_large(tag, P):
     """Ragged sample counts through the automatic (MFMA) path, three field configurations, vs the oracle."""
     z = load_golden("g1_onf.npz")
@@ -331,14 +331,15 @@ def test_onf_training_mfma_path_vs_oracle_large(tag, P):
     x += rng.normal(0, 0.05, x.shape).astype(F32)
     y = (rng.uniform(size=P) < 0.4).astype(F32)
     g_auto = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 0)
-    g_ps = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 1)
     loss, _, gref = orc.onf_train_grads(z[tag + "_params"], cfg, x, y)
     scale = max(1.0, float(np.abs(gref).max()))
     assert abs(float(g_auto[-2]) - float(loss)) < 5e-6 * max(1.0, abs(float(loss)))
     assert max_abs(g_auto[:-2], gref) < 2e-5 * scale
-    assert max_abs(g_ps[:-2], gref) < 2e-5 * scale
-    # the two device paths differ only by summation order
-    assert max_abs(g_auto[:-2], g_ps[:-2]) < 2e-5 * scale
+    if P <= 65536:      # the per-sample path (small fits) takes at most 65536 samples
+        g_ps = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 1)
+        assert max_abs(g_ps[:-2], gref) < 2e-5 * scale
+        # the two device paths differ only by summation order
+        assert max_abs(g_auto[:-2], g_ps[:-2]) < 2e-5 * scale
     # bitwise reproducible
     g_again = _train_grad(onf, torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda"), 0)
     assert np.array_equal(g_auto, g_again)
