@@ -43,6 +43,9 @@ int launch_onf_kernel(const OnfKernelArgs& a, hipStream_t stream);
 int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only);
 int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);
 bool onf_split_enabled();
+// csrc/onf_x32.hip: the bf16x3 split path on 32x32x16 tiles (mode 0 / 2), one 32-sample tile per wave
+bool onf_x32_supports(const OnfGeom& g);
+int launch_onf_x32_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only);
 int launch_onf_logits_kernel(const OnfKernelArgs& a, hipStream_t stream);
 int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);
 int onf_train_grid_upper_bound();

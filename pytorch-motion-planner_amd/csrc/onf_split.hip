@@ -1034,14 +1034,27 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-static int g_split_mode = -1;   // -1: read NFOPP_MATRIX_PATH on first use; 0: fp32 MFMA; 1: bf16x3 split (default)
+// -1: read NFOPP_MATRIX_PATH on first use; 0: fp32 MFMA; 1: bf16x3 split (default: the 32x32x16 kernel of csrc/onf_x32.hip
+// for launches that give every CU a full chunk, this file's 16x16x32 kernel for small launches and the training pass);
+// 2: bf16x3 split, this file's kernel at every size; 3: bf16x3 split, the 32x32x16 kernel at every size (tests)
+static int g_split_mode = -1;
 
-bool onf_split_enabled() {
+static int split_mode() {
   if (g_split_mode < 0) {
     const char* e = getenv("NFOPP_MATRIX_PATH");
-    g_split_mode = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;   // "fp32" / "0" select the fp32 MFMA kernels
+    g_split_mode = !e ? 1 : (e[0] == 'f' || e[0] == '0') ? 0 : (e[0] == '2' || e[0] == 's') ? 2 : (e[0] == '3' || e[0] == 'x') ? 3 : 1;
   }
-  return g_split_mode == 1;
+  return g_split_mode;
+}
+
+bool onf_split_enabled() { return split_mode() >= 1; }
+
+// the 32x32x16 kernel takes the launch when it covers the feature dimension and the launch fills the chip
+bool onf_use_x32(const OnfGeom& g, long long n_points) {
+  const int m = split_mode();
+  if (m != 1 && m != 3) return false;
+  if (!onf_x32_supports(g)) return false;
+  return m == 3 || n_points >= (long long)query_cus() * 256;
 }
 
 // Third-level blobs.  split_prep_kernel rewrites the blob in front of every launch ON THE LAUNCH STREAM, so launches of
@@ -1162,6 +1175,7 @@ int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, in
 
 int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only) {
   if (a.n_points <= 0) return NFOPP_OK;
+  if (onf_use_x32(a.geom, a.n_points)) return launch_onf_x32_kernel(a, stream, forward_only);
   return forward_only ? launch_split_mode<2>(a, stream) : launch_split_mode<0>(a, stream);
 }
 
@@ -1170,9 +1184,11 @@ int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool for
 using namespace nfopp;
 
 extern "C" int nfopp_set_matrix_path(int32_t path) {
-  NFOPP_REQUIRE(path == 0 || path == 1, "matrix path must be 0 (fp32 MFMA) or 1 (bf16x3 split MFMA)");
+  NFOPP_REQUIRE(path >= 0 && path <= 3,
+                "matrix path must be 0 (fp32 MFMA), 1 (bf16x3 split MFMA), 2 (split, 16x16x32 kernel only) or 3 (split, 32x32x16 "
+                "kernel at every size)");
   g_split_mode = path;
   return NFOPP_OK;
 }
 
-extern "C" int nfopp_get_matrix_path(void) { return onf_split_enabled() ? 1 : 0; }
+extern "C" int nfopp_get_matrix_path(void) { return split_mode(); }

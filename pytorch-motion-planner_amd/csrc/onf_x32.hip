@@ -1,0 +1,763 @@
+// K1 on 32x32x16 tiles: fused collision sampling + ONF forward + input gradient for gfx950, every GEMM on the bf16 matrix
+// pipe as an exact three-level split of the fp32 operands (the arithmetic of csrc/onf_split.hip: x = hi + mid + lo, six
+// partial products per multiply, fp32 accumulation).  Reference: nfop/onf_model.py:33-50 + autograd, nfop/angle_encoder.py:
+// 15-18, the collision sampling of nfop/constrained_nerf_opt_planner.py:78-81 (csrc/onf_layout.h: load_point).
+//
+// Why a second formulation (round 3).  onf_split.hip (16x16x32 tiles, two 16-point tiles per wave) ran at 49 % of the
+// matrix pipe with 4.2 vector instructions per MFMA: a v_mfma_f32_16x16x32_bf16 holds the SIMD's vector issue port for 8 of
+// its 16 cycles, every weight fragment cost 8 ds_read_b32 + 8 v_perm_b32, and biases / skip connection / ReLU masks were
+// vector work.  Here
+//  * one wave owns ONE tile of 32 samples; v_mfma_f32_32x32x16_bf16 holds the issue port for 8 of its 32 cycles, so the
+//    vector work of a step (feature evaluation, operand splitting, chain-rule epilogue) fits behind its MFMAs;
+//  * the hi and the mid level of the weights are two bf16 MATRICES per layer in LDS, M[output position][input slot]
+//    (144 KB), read as finished A fragments: ds_read_b128 in the forward GEMMs, ds_read_b64_tr_b16 in the transposed ones,
+//    both conflict-free on the same swizzled image (tools/x32/lds_search.py); no permutes, 2 (4) LDS instructions per step;
+//  * b1, b2, b3 and the skip connection W3[100:] ride in spare rows / columns of the padded matrices: input position `fin`
+//    is a constant-one feature (column = b1), hidden row 100 is the skip row (W3b | b3 -> its pre-activation IS the skip
+//    part of the logit, and dh1[100] := 1 adds W3b to the input gradient), hidden row 101 regenerates the constant one
+//    (column 101 of W2 = b2);
+//  * the third level stays in an L2-resident blob in consumption order (one 16-byte buffer load per lane and step).
+// Accumulator chaining as before: a 32x32 result tile is the next GEMM's B operand with the k order permuted inside a
+// 16-block -- slot 16 kb + 8 g + e  <->  position 16 kb + 8 (e >> 2) + 4 g + (e & 3) -- and the images are stored in slot
+// order, so L1 -> L2 -> L2^T -> L1^T never leaves registers.  tools/x32/emulate_x32.py checks every address formula
+// below, lane by lane, against a plain MLP (CPU).
+//
+// Modes: 0 forward + input gradient, 2 forward only.  The training pass (factors for the weight-gradient GEMMs) stays on
+// onf_split.hip.  Small launches (fewer samples than one 256-sample chunk per CU) also stay there: its 16-sample tiles
+// spread them over more CUs.
+#include <stdlib.h>
+
+#include <mutex>
+#include <type_traits>
+
+#include "onf_layout.h"
+
+namespace nfopp {
+namespace x32 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int V> using ic = std::integral_constant<int, V>;
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(ic<I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+// ---- geometry of the LDS image (bytes) ---------------------------------------------------------------------------
+constexpr int RS1 = 448, RS2 = 256;            // row strides of the W1 / W2 images (224 / 112 bf16 slots + swizzle room)
+constexpr int W1_ROWS = 103, W2_ROWS = 101;    // hidden rows 0..99 | 100 skip | 101 ones | zero row;  0..99 | zero row
+constexpr int W1_ZERO = 102, W2_ZERO = 100;
+constexpr int SKIP = 100, ONES = 101;
+constexpr int HK = 7;                          // hidden k steps of 16 slots (positions 0..111)
+constexpr int up256(int x) { return (x + 255) / 256 * 256; }
+// every image starts on a multiple of 256 bytes: the W2 read addresses are formed with XORs on the low 8 bits
+constexpr int O_W1H = 0;
+constexpr int O_W1M = up256(O_W1H + W1_ROWS * RS1);
+constexpr int O_W2H = up256(O_W1M + W1_ROWS * RS1);
+constexpr int O_W2M = up256(O_W2H + W2_ROWS * RS2);
+constexpr int O_FT = up256(O_W2M + W2_ROWS * RS2);    // [224] (c0, c1, b, q): forward feature table by input position
+constexpr int O_FTD = O_FT + 224 * 16;         // the same with q + a quarter turn: d feature / d argument
+constexpr int O_ISA = O_FTD + 224 * 16;        // [224] 1.0 = angle feature
+constexpr int O_W3A = O_ISA + 224 * 4;         // [128] fp32 W3[:100] by hidden position
+constexpr int O_W3L = O_W3A + 128 * 4;         // [7 kb][2 g][3 levels][4 words]: W3[:100] pre-split in B-fragment order
+constexpr int IMG_BYTES = O_W3L + HK * 2 * 3 * 16;
+static_assert(IMG_BYTES % 16 == 0 && IMG_BYTES <= 160 * 1024, "LDS image");
+
+__host__ __device__ constexpr int pos_of_slot(int s) {
+  return 16 * (s >> 4) + 8 * ((s >> 2) & 1) + 4 * ((s >> 3) & 1) + (s & 3);
+}
+__host__ __device__ constexpr int swz1(int row) { return (row >> 2) & 3; }
+__host__ __device__ constexpr int swz2(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int NKB>
+struct Cfg {
+  static constexpr int NMT = (NKB + 1) / 2;        // 32-position output tiles of L1^T
+  static constexpr int FS = NKB >= 13 ? 12 : 6;    // n_enc / 16: first input k block that can hold angle / ones / pad features
+  static constexpr int S_L1 = 0, S_L2 = S_L1 + 4 * NKB, S_L2T = S_L2 + 4 * HK, S_L1T = S_L2T + 4 * HK;
+  static constexpr int STEPS = S_L1T + HK * NMT;
+  static constexpr size_t BLOB_BYTES = size_t(STEPS + 4) * 1024;   // + the three-step look-ahead past the last step
+};
+
+// ---- extended weight matrices (the folded biases / skip row / ones unit) ---------------------------------------
+__device__ __forceinline__ float w1ext(const OnfGeom& g, const float* P, int row, int f) {
+  if (row < H) return f < g.fin ? P[g.off_w1 + row * g.fin + f] : (f == g.fin ? P[g.off_b1 + row] : 0.0f);
+  if (row == SKIP) return f < g.fin ? P[g.off_w3 + H + f] : (f == g.fin ? P[g.off_b3] : 0.0f);
+  if (row == ONES) return f == g.fin ? 1.0f : 0.0f;
+  return 0.0f;
+}
+__device__ __forceinline__ float w2ext(const OnfGeom& g, const float* P, int row, int hp) {
+  if (row >= H) return 0.0f;
+  if (hp < H) return P[g.off_w2 + row * H + hp];
+  return hp == ONES ? P[g.off_b2 + row] : 0.0f;
+}
+__device__ __forceinline__ unsigned level_of(float w, int lvl) {
+  unsigned r = split_level(w);
+  if (lvl >= 1) r = split_level(w);
+  if (lvl >= 2) r = __float_as_uint(w) >> 16;
+  return r;
+}
+__device__ __forceinline__ u32x4 pack_level(const float (&w)[8], int lvl) {
+  u32x4 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) o[p] = level_of(w[2 * p], lvl) | (level_of(w[2 * p + 1], lvl) << 16);
+  return o;
+}
+
+// One thread per 16-byte piece of the LDS image and of the third-level blob.
+template <int NKB>
+__global__ __launch_bounds__(256) void x32_prep_kernel(const OnfGeom geo, const float* __restrict__ P, u32x4* __restrict__ img,
+                                                       u32x4* __restrict__ blob) {
+  using C = Cfg<NKB>;
+  constexpr int N_IMG = IMG_BYTES / 16, N_BLOB = (C::STEPS + 4) * 64;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N_IMG + N_BLOB) return;
+  if (idx >= N_IMG) {   // ---- blob: step (gemm, kb, mt), lane -> the lane's 8 weights, third level
+    const int b = idx - N_IMG, step = b >> 6, lane = b & 63, i = lane & 31, g = lane >> 5;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = 0.0f;
+    if (step < C::STEPS) {
+      int kb, mt, kind;
+      if (step < C::S_L2) { kind = 0; kb = step >> 2; mt = step & 3; }
+      else if (step < C::S_L2T) { kind = 1; kb = (step - C::S_L2) >> 2; mt = (step - C::S_L2) & 3; }
+      else if (step < C::S_L1T) { kind = 2; kb = (step - C::S_L2T) >> 2; mt = (step - C::S_L2T) & 3; }
+      else { kind = 3; mt = (step - C::S_L1T) / HK; kb = (step - C::S_L1T) % HK; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int p = pos_of_slot(16 * kb + 8 * g + e), m = 32 * mt + i;
+        w[e] = kind == 0 ? w1ext(geo, P, m, p) : kind == 1 ? w2ext(geo, P, m, p) : kind == 2 ? w2ext(geo, P, p, m)
+                                                                                            : w1ext(geo, P, p, m);
+      }
+    }
+    blob[b] = pack_level(w, 2);
+    return;
+  }
+  const int byte = idx * 16;
+  u32x4 out = {0u, 0u, 0u, 0u};
+  if (byte < O_W2H) {          // W1 images: physical chunk c of row r holds logical chunk c ^ swz1(r)
+    const int lvl = byte >= O_W1M ? 1 : 0, rel = byte - (lvl ? O_W1M : O_W1H), row = rel / RS1, ch = ((rel % RS1) >> 4) ^ swz1(row);
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = row < W1_ROWS ? w1ext(geo, P, row, pos_of_slot(8 * ch + e)) : 0.0f;
+    out = pack_level(w, lvl);
+  } else if (byte < O_FT) {    // W2 images
+    const int lvl = byte >= O_W2M ? 1 : 0, rel = byte - (lvl ? O_W2M : O_W2H), row = rel / RS2, ch = ((rel % RS2) >> 4) ^ swz2(row);
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = (row < W2_ROWS && (8 * ch + e) < 16 * HK) ? w2ext(geo, P, row, pos_of_slot(8 * ch + e)) : 0.0f;
+    out = pack_level(w, lvl);
+  } else if (byte < O_ISA) {   // feature tables: sin(arg + q pi/2), q in revolutions (v_sin_f32 unit); FTD: + a quarter turn
+    const bool deriv = byte >= O_FTD;
+    const int f = (byte - (deriv ? O_FTD : O_FT)) >> 4;
+    float c0 = 0.f, c1 = 0.f, b = 0.f, q = 0.f;
+    if (f < geo.n_enc) {         // encoding_layer: W_e u + b_e (onf_model.py:39), cosine half: onf_model.py:41
+      c0 = P[geo.off_we + 2 * f]; c1 = P[geo.off_we + 2 * f + 1];
+      b = geo.off_be >= 0 ? P[geo.off_be + f] : 0.0f;
+      q = (geo.n_enc > geo.n_sin && f >= geo.n_sin) ? 0.25f : 0.0f;
+    } else if (f < geo.fin) {    // angle_encoder.py:16: (theta + b) * f
+      const int k = f - geo.n_enc;
+      c0 = P[geo.off_ang_f + k]; b = P[geo.off_ang_b + k];
+      q = k >= geo.ang_dim ? 0.25f : 0.0f;
+    } else if (f == geo.fin) {
+      q = 0.25f;                 // the ones feature (its value is forced to exactly 1 where it is evaluated)
+    }
+    if (deriv) q += 0.25f;
+    out = u32x4{__float_as_uint(c0), __float_as_uint(c1), __float_as_uint(b), __float_as_uint(q)};
+  } else if (byte < O_W3A) {
+    const int f0 = (byte - O_ISA) >> 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = __float_as_uint((f0 + k >= geo.n_enc && f0 + k < geo.fin) ? 1.0f : 0.0f);
+  } else if (byte < O_W3L) {
+    const int p0 = (byte - O_W3A) >> 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = __float_as_uint(p0 + k < H ? P[geo.off_w3 + p0 + k] : 0.0f);
+  } else {
+    const int t = (byte - O_W3L) >> 4, lvl = t % 3, g = (t / 3) & 1, kb = t / 6;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = pos_of_slot(16 * kb + 8 * g + e);
+      w[e] = p < H ? P[geo.off_w3 + p] : 0.0f;
+    }
+    out = pack_level(w, lvl);
+  }
+  img[idx] = out;
+}
+
+// ---- device helpers ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 lds128(const unsigned char* lds, int byte) {
+  return *reinterpret_cast<const u32x4*>(lds + byte);
+}
+__device__ __forceinline__ f32x4 lds128f(const unsigned char* lds, int byte) {
+  return *reinterpret_cast<const f32x4*>(lds + byte);
+}
+// two transposing reads = the 8 k values of a transposed A fragment (rows 8 apart in k: byte distance `d8`)
+__device__ __forceinline__ u32x4 lds_tr(const unsigned char* lds, int byte0, int byte1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + byte0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + byte1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(u32x4, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+}
+
+// 6 partial products of one step (smallest terms first); WORK(slot) runs behind MFMA number slot - SLOT0
+template <int SLOT0, class W>
+__device__ __forceinline__ void step6(f32x16& acc, const u32x4& ah, const u32x4& am, const u32x4& al, const u32x4 (&b)[3],
+                                      W&& work) {
+  acc = mfma32(al, b[0], acc); work(ic<SLOT0 + 0>{}); __builtin_amdgcn_sched_barrier(0);
+  acc = mfma32(ah, b[2], acc); work(ic<SLOT0 + 1>{}); __builtin_amdgcn_sched_barrier(0);
+  acc = mfma32(am, b[1], acc); work(ic<SLOT0 + 2>{}); __builtin_amdgcn_sched_barrier(0);
+  acc = mfma32(am, b[0], acc); work(ic<SLOT0 + 3>{}); __builtin_amdgcn_sched_barrier(0);
+  acc = mfma32(ah, b[1], acc); work(ic<SLOT0 + 4>{}); __builtin_amdgcn_sched_barrier(0);
+  acc = mfma32(ah, b[0], acc); work(ic<SLOT0 + 5>{}); __builtin_amdgcn_sched_barrier(0);
+}
+
+// one instruction of the exact pair split (11 per pair): x0, x1 -> one word of each level
+struct SplitState { unsigned ta, tb; float ra, rb, la, lb; };
+template <int U>
+__device__ __forceinline__ void split_item(SplitState& s, float x0, float x1, u32x4 (&out)[3], int p) {
+  if constexpr (U == 0) out[0][p] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302);
+  if constexpr (U == 1) s.ta = __float_as_uint(x0) & 0xffff0000u;
+  if constexpr (U == 2) s.tb = __float_as_uint(x1) & 0xffff0000u;
+  if constexpr (U == 3) s.ra = x0 - __uint_as_float(s.ta);
+  if constexpr (U == 4) s.rb = x1 - __uint_as_float(s.tb);
+  if constexpr (U == 5) out[1][p] = __builtin_amdgcn_perm(__float_as_uint(s.rb), __float_as_uint(s.ra), 0x07060302);
+  if constexpr (U == 6) s.ta = __float_as_uint(s.ra) & 0xffff0000u;
+  if constexpr (U == 7) s.tb = __float_as_uint(s.rb) & 0xffff0000u;
+  if constexpr (U == 8) s.la = s.ra - __uint_as_float(s.ta);
+  if constexpr (U == 9) s.lb = s.rb - __uint_as_float(s.tb);
+  if constexpr (U == 10) out[2][p] = __builtin_amdgcn_perm(__float_as_uint(s.lb), __float_as_uint(s.la), 0x07060302);
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, u32x4 (&out)[3], int p) {
+  SplitState s;
+  sfor<0, 11>([&](auto u) { split_item<decltype(u)::value>(s, x0, x1, out, p); });
+}
+
+// one instruction of a feature evaluation sin(arg + q) (hardware path of common.h: sin_halfturns_hw), 8 per feature
+struct EvalState { float arg, t, j, r, v; };
+template <int U>
+__device__ __forceinline__ void eval_item(EvalState& s, const f32x4& tw, float ux, float uy) {
+  if constexpr (U == 0) s.arg = fmaf(tw.y, uy, tw.z);
+  if constexpr (U == 1) s.arg = fmaf(tw.x, ux, s.arg);
+  if constexpr (U == 2) s.t = fmaf(s.arg, 0.159154943f, 12582912.0f);
+  if constexpr (U == 3) s.j = s.t - 12582912.0f;
+  if constexpr (U == 4) s.r = fmaf(s.j, -6.28318548202514648f, s.arg);
+  if constexpr (U == 5) s.r = fmaf(s.j, 1.74845553e-07f, s.r);
+  if constexpr (U == 6) s.v = fmaf(s.r, 0.159154943f, tw.w);
+  if constexpr (U == 7) s.v = __builtin_amdgcn_sinf(s.v);
+}
+
+constexpr int CH = 8 * 32;   // samples per workgroup pass: 8 waves x one 32-sample tile
+
+template <int NKB, int MODE>
+__global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, const u32x4* __restrict__ img,
+                                                         const u32x4* __restrict__ blob) {
+  using C = Cfg<NKB>;
+  constexpr bool FWD_ONLY = MODE == 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  {   // image -> LDS, four 16-byte pieces per thread in flight
+    constexpr int N16 = IMG_BYTES / 16;
+    for (int k0 = threadIdx.x; k0 < N16; k0 += 4 * 512) {
+      u32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (k0 + 512 * q < N16) v[q] = img[k0 + 512 * q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (k0 + 512 * q < N16) reinterpret_cast<u32x4*>(lds)[k0 + 512 * q] = v[q];
+    }
+  }
+  __syncthreads();
+  // static priority for the younger half (MI355X_MICROARCH.md); the condition must be provably wave-uniform, or hipcc
+  // lowers it to an exec mask around an UNCONDITIONAL s_setprio
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+
+  const OnfGeom& geo = a.geom;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  // ---- lane parts of every LDS address (formulas: tools/x32/emulate_x32.py) ----
+  const int xs = (j >> 2) & 3;
+  const int lowE = 16 * ((g ^ xs) & 3), lowO = 16 * (((2 | g) ^ xs) & 3);
+  const int row31 = min(96 + j, W1_ZERO), row32 = min(96 + j, W2_ZERO);
+  // forward W1: + 64 (kb >> 1) + 32 * RS1 * mt; [parity of kb][tile 3 ?]
+  int w1f[2][2] = {{j * RS1 + lowE, row31 * RS1 + lowE}, {j * RS1 + lowO, row31 * RS1 + lowO}};
+  // forward W2: (base ^ (kb << 5)) + 32 * RS2 * mt
+  const int sw2 = 16 * swz2(j);
+  int w2f[2] = {(j * RS2 + sw2) ^ (g << 4), (row32 * RS2 + sw2) ^ (g << 4)};
+  // Left to itself hipcc forms every (lane base + image offset + tile offset) once, in front of the persistent loop --
+  // some 200 registers -- and spills them; an empty asm at the start of each GEMM makes the few lane bases opaque so
+  // that the sums are formed where they are used (the same device as onf_split.hip's NFOPP_REDERIVE).
+#define X32_OPAQUE2(A) asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]))
+  // transposed reads: lane = (g, a, q, p)
+  const int ta = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+  int t2[2][2], t1[2][2];   // [eh][kb == 6 ?]
+#pragma unroll
+  for (int eh = 0; eh < 2; ++eh) {
+    const int low = 16 * (((2 * ta + (tp & 1)) ^ (2 * eh + g)) & 3) + 8 * (tp >> 1);
+    const int r = 8 * eh + 4 * g + tq;
+    t2[eh][0] = r * RS2 + 64 * tq + low;                          // (^ (mt << 6)) + 16 * RS2 * kb
+    t2[eh][1] = min(96 + r, W2_ZERO) * RS2 + 64 * tq + low;
+    t1[eh][0] = r * RS1 + low;                                    // + 16 * RS1 * kb + 64 * mt
+    t1[eh][1] = min(96 + r, W1_ZERO) * RS1 + low;
+  }
+  int ftl = O_FT + 64 * g, ftdl = O_FTD + 64 * g, isl = O_ISA + 16 * g, w3al = O_W3A + 16 * g, w3ll = O_W3L + 48 * g;
+  int fin_rel = geo.fin - 4 * g;   // position == fin  <=>  16 kb + 8 (e >> 2) + (e & 3) == fin_rel
+
+  const unsigned lane16 = lane * 16;
+  const __amdgpu_buffer_rsrc_t blob_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(blob), 0, (int)C::BLOB_BYTES, 0x00020000);
+  auto lo_frag = [&](int step) __attribute__((always_inline)) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane16, step * 1024, 0));
+  };
+
+  const long long n_work = work_points(a);
+  const long long n_chunks = (n_work + CH - 1) / CH;
+
+  for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    float ux, uy, th;
+    long long pidx;
+    // table bases: opaque per chunk, so that (base + small constant) stays an immediate offset of the LDS read instead
+    // of one hoisted register per constant
+    asm volatile("" : "+v"(ftl), "+v"(ftdl), "+v"(isl), "+v"(w3al), "+v"(w3ll), "+v"(fin_rel));
+    {
+      float x, y, ang;
+      pidx = load_point(a, n_work, chunk * CH + wave * 32 + j, g, x, y, ang);
+      ux = (x - geo.mean) / geo.sigma;
+      uy = (y - geo.mean) / geo.sigma;
+      th = ang;
+    }
+    // third-level fragments: ring of 4, three steps ahead, running on across the GEMMs (blob steps are consecutive)
+    u32x4 fl[4];
+    fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
+    u32x4 fh[2], fm[2];   // hi / mid fragments: this step and the next
+
+    // generic evaluation of one input feature (any kind), used for the first block and the angle / ones / pad blocks
+    auto feature_any = [&](auto special_c, int kb, int e) __attribute__((always_inline)) {
+      constexpr bool SPECIAL = decltype(special_c)::value;   // the block may hold angle / ones / pad positions
+      const int off = 256 * kb + 128 * (e >> 2) + 16 * (e & 3);
+      const f32x4 tw = lds128f(lds, ftl + off);
+      float arg = fmaf(tw.x, ux, fmaf(tw.y, uy, tw.z));
+      if constexpr (SPECIAL) {
+        const float isa = *reinterpret_cast<const float*>(lds + isl + (off >> 2));
+        const float za = (th + tw.z) * tw.x;
+        arg = isa != 0.0f ? za : arg;
+      }
+      const float v = sin_halfturns_hw(arg, tw.w);
+      if constexpr (SPECIAL) return (16 * kb + 8 * (e >> 2) + (e & 3)) == fin_rel ? 1.0f : v;
+      else return v;
+    };
+    auto features_upfront = [&](auto special_c, int kb, u32x4 (&out)[3]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) split_pair(feature_any(special_c, kb, 2 * p), feature_any(special_c, kb, 2 * p + 1), out, p);
+    };
+
+    // ================================================================ L1: a1 = W1ext in
+    f32x16 acc1[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+    {
+      u32x4 bA[3], bB[3];
+      features_upfront(std::false_type{}, 0, bA);
+      // hooked preparation of the NEXT block's fragments: 4 pairs x (16 evaluation + 11 split) instructions, 5 per slot.
+      // Schedule (work item w): E0 E1 S0 E2 S1 E3 S2 S3; table entries of pair p+1 are loaded at the start of E(p).
+      f32x4 tw[2][2];
+      float fv[8];
+      EvalState es[2];
+      SplitState ss;
+      int nxt_ft = 0;   // table byte address of the block being prepared
+      auto load_pair = [&](int p) __attribute__((always_inline)) {
+        const int off = nxt_ft + 128 * ((2 * p) >> 2) + 16 * ((2 * p) & 3);
+        tw[p & 1][0] = lds128f(lds, off);
+        tw[p & 1][1] = lds128f(lds, off + 16);
+      };
+      auto l1_item = [&](auto wc, u32x4 (&out)[3]) __attribute__((always_inline)) {
+        constexpr int w = decltype(wc)::value;
+        constexpr int seg = w < 16 ? 0 : w < 32 ? 1 : w < 43 ? 2 : w < 59 ? 3 : w < 70 ? 4 : w < 86 ? 5 : w < 97 ? 6 : w < 108 ? 7 : 8;
+        constexpr int start[9] = {0, 16, 32, 43, 59, 70, 86, 97, 108};
+        constexpr int evp[9] = {0, 1, -1, 2, -1, 3, -1, -1, -1}, spp[9] = {-1, -1, 0, -1, 1, -1, 2, 3, -1};
+        constexpr int u = w - start[seg];
+        if constexpr (evp[seg] >= 0) {
+          constexpr int p = evp[seg], which = u & 1, st = u >> 1;
+          if constexpr (u == 0 && p < 3) load_pair(p + 1);
+          eval_item<st>(es[which], tw[p & 1][which], ux, uy);
+          if constexpr (st == 7) fv[2 * p + which] = es[which].v;
+        } else if constexpr (spp[seg] >= 0) {
+          constexpr int p = spp[seg];
+          split_item<u>(ss, fv[2 * p], fv[2 * p + 1], out, p);
+        }
+      };
+      // MFMA steps of block kb (fragments in bc), preparing block kb + 1 into bn when HOOK
+      auto l1_block = [&](auto hook_c, auto par_c, int kb, const u32x4 (&bc)[3], u32x4 (&bn)[3]) __attribute__((always_inline)) {
+        constexpr bool HOOK = decltype(hook_c)::value;
+        constexpr int PAR = decltype(par_c)::value;   // parity of kb
+        const int kq = 64 * (kb >> 1);
+        if constexpr (HOOK) { nxt_ft = ftl + 256 * (kb + 1); load_pair(0); }
+        sfor<0, 4>([&](auto mtc) {
+          constexpr int mt = decltype(mtc)::value;
+          // this step's hi / mid were fetched one step ago; fetch the next step's (past the last block: a harmless
+          // in-image read)
+          if constexpr (mt < 3) {
+            const int ad = w1f[PAR][mt + 1 == 3] + kq + (mt + 1 < 3 ? 32 * RS1 * (mt + 1) : 0);
+            fh[(mt + 1) & 1] = lds128(lds, O_W1H + ad); fm[(mt + 1) & 1] = lds128(lds, O_W1M + ad);
+          } else {
+            const int ad = w1f[PAR ^ 1][0] + 64 * ((kb + 1) >> 1);
+            fh[0] = lds128(lds, O_W1H + ad); fm[0] = lds128(lds, O_W1M + ad);
+          }
+          fl[(mt + 3) & 3] = lo_frag(C::S_L1 + 4 * kb + mt + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          step6<6 * mt>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[mt], bc, [&](auto slot) {
+            if constexpr (HOOK) sfor<0, 5>([&](auto i) { l1_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}, bn); });
+          });
+        });
+      };
+      constexpr int FS = C::FS;
+      X32_OPAQUE2(w1f);
+      fh[0] = lds128(lds, O_W1H + w1f[0][0]); fm[0] = lds128(lds, O_W1M + w1f[0][0]);
+#pragma unroll 1
+      for (int kp = 0; kp < FS / 2 - 1; ++kp) {
+        l1_block(std::true_type{}, ic<0>{}, 2 * kp, bA, bB);
+        l1_block(std::true_type{}, ic<1>{}, 2 * kp + 1, bB, bA);
+      }
+      l1_block(std::true_type{}, ic<0>{}, FS - 2, bA, bB);
+      l1_block(std::false_type{}, ic<1>{}, FS - 1, bB, bA);
+      // blocks with angle / ones / pad features: evaluated up front
+      sfor<FS, NKB>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        features_upfront(std::true_type{}, kb, bA);
+        l1_block(std::false_type{}, ic<(kb & 1)>{}, kb, bA, bB);
+      });
+    }
+    const float skipv = acc1[3][0];   // position 100 = tile 3, g = 1, register 0: W3b . in + b3 (lanes g = 1)
+
+    // ================================================================ L2: a2 = W2ext relu(a1)
+    f32x16 acc2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+    unsigned m1w[2] = {0u, 0u};   // [a1 > 0]: block kb, element e -> word kb >> 2, pushed from the low end in order
+    asm volatile("" : "+v"(w2f[0]), "+v"(w2f[1]));
+    {
+      u32x4 bb[2][3];
+      float hv[2];
+      SplitState ss;
+      // relu + sign + split of one pair of block kb: 6 + 11 instructions
+      auto h1_item = [&](auto kbc, auto wc, u32x4 (&out)[3]) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value, w = decltype(wc)::value;
+        if constexpr (w < 68) {
+          constexpr int p = w / 17, u = w % 17, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p;
+          if constexpr (u == 0) hv[0] = relu1(acc1[t][r0]);
+          if constexpr (u == 1) hv[1] = relu1(acc1[t][r0 + 1]);
+          if constexpr (u == 2) m1w[kb >> 2] = __builtin_amdgcn_alignbit(m1w[kb >> 2], 0u - __float_as_uint(hv[0]), 31);
+          if constexpr (u == 3) m1w[kb >> 2] = __builtin_amdgcn_alignbit(m1w[kb >> 2], 0u - __float_as_uint(hv[1]), 31);
+          if constexpr (u >= 4 && u < 15) split_item<u - 4>(ss, hv[0], hv[1], out, p);
+        }
+      };
+      sfor<0, 68>([&](auto w) { h1_item(ic<0>{}, w, bb[0]); });
+      sfor<0, HK>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        const int kx = kb << 5;
+        sfor<0, 4>([&](auto mtc) {
+          constexpr int mt = decltype(mtc)::value;
+          if constexpr (mt == 0 && kb == 0) {
+            fh[0] = lds128(lds, O_W2H + w2f[0]); fm[0] = lds128(lds, O_W2M + w2f[0]);
+          }
+          if constexpr (mt < 3) {
+            const int ad = (w2f[mt + 1 == 3] ^ kx) + (mt + 1 < 3 ? 32 * RS2 * (mt + 1) : 0);
+            fh[(mt + 1) & 1] = lds128(lds, O_W2H + ad); fm[(mt + 1) & 1] = lds128(lds, O_W2M + ad);
+          } else if constexpr (kb + 1 < HK) {
+            const int ad = w2f[0] ^ ((kb + 1) << 5);
+            fh[0] = lds128(lds, O_W2H + ad); fm[0] = lds128(lds, O_W2M + ad);
+          }
+          fl[(mt + 3) & 3] = lo_frag(C::S_L2 + 4 * kb + mt + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          step6<6 * mt>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+            if constexpr (kb + 1 < HK)
+              sfor<0, 3>([&](auto i) { h1_item(ic<kb + 1>{}, ic<3 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
+          });
+        });
+      });
+    }
+
+    if constexpr (FWD_ONLY) {
+      float lg = 0.0f;
+      sfor<0, 4>([&](auto mtc) {
+        constexpr int mt = decltype(mtc)::value;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 w3a = lds128f(lds, w3al + 128 * mt + 32 * q4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lg = fmaf(w3a[r], relu1(acc2[mt][4 * q4 + r]), lg);
+        }
+      });
+      lg += g == 1 ? skipv : 0.0f;
+      lg += __shfl_xor(lg, 32);
+      if (g == 0 && pidx < a.n_points) *reinterpret_cast<f32x4*>(a.out4 + pidx * 4) = f32x4{lg, 0.f, 0.f, 0.f};
+      continue;
+    }
+
+    // ================================================================ L2^T: W2ext^T dh2,  dh2 = W3a [a2 > 0]; the logit on the way
+    f32x16 accd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[mt][r] = 0.0f;
+    float lgs[2] = {0.0f, 0.0f};
+    X32_OPAQUE2(t2);
+    {
+      u32x4 bb[2][3];
+      f32x4 w3f[2];     // fp32 W3a of the block's 8 positions
+      u32x4 w3c[3];     // its pre-split levels, B-fragment order
+      float hv[2];
+      unsigned mk[2];
+      auto dh2_load = [&](int kb) __attribute__((always_inline)) {
+        w3f[0] = lds128f(lds, w3al + 64 * kb); w3f[1] = lds128f(lds, w3al + 64 * kb + 32);
+        w3c[0] = lds128(lds, w3ll + 96 * kb); w3c[1] = lds128(lds, w3ll + 96 * kb + 16); w3c[2] = lds128(lds, w3ll + 96 * kb + 32);
+      };
+      // one pair of block kb: relu, sign mask, logit terms, masked level words: 12 instructions
+      auto dh2_item = [&](auto kbc, auto wc, u32x4 (&out)[3]) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value, w = decltype(wc)::value;
+        if constexpr (w < 48) {
+          constexpr int p = w / 12, u = w % 12, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p, e0 = 2 * p;
+          if constexpr (u == 0) hv[0] = relu1(acc2[t][r0]);
+          if constexpr (u == 1) hv[1] = relu1(acc2[t][r0 + 1]);
+          if constexpr (u == 2) mk[0] = 0u - __float_as_uint(hv[0]);
+          if constexpr (u == 3) mk[1] = 0u - __float_as_uint(hv[1]);
+          if constexpr (u == 4) mk[0] = (unsigned)((int)mk[0] >> 31);
+          if constexpr (u == 5) mk[1] = (unsigned)((int)mk[1] >> 31);
+          if constexpr (u == 6) lgs[0] = fmaf(w3f[e0 >> 2][e0 & 3], hv[0], lgs[0]);
+          if constexpr (u == 7) lgs[1] = fmaf(w3f[(e0 + 1) >> 2][(e0 + 1) & 3], hv[1], lgs[1]);
+          if constexpr (u == 8) mk[0] = __builtin_amdgcn_perm(mk[1], mk[0], 0x07060302);
+          if constexpr (u == 9) out[0][p] = w3c[0][p] & mk[0];
+          if constexpr (u == 10) out[1][p] = w3c[1][p] & mk[0];
+          if constexpr (u == 11) out[2][p] = w3c[2][p] & mk[0];
+        }
+      };
+      dh2_load(0);
+      sfor<0, 48>([&](auto w) { dh2_item(ic<0>{}, w, bb[0]); });
+      sfor<0, HK>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        constexpr int Z = kb == 6;
+        if constexpr (kb + 1 < HK) dh2_load(kb + 1);
+        sfor<0, 4>([&](auto mtc) {
+          constexpr int mt = decltype(mtc)::value;
+          auto fetch = [&](int kbn, int mtn, int zn, int slot) __attribute__((always_inline)) {
+            const int a0 = (t2[0][zn] ^ (mtn << 6)) + (zn ? 0 : 16 * RS2 * kbn);
+            const int a1 = (t2[1][zn] ^ (mtn << 6)) + (zn ? 0 : 16 * RS2 * kbn);
+            fh[slot] = lds_tr(lds, O_W2H + a0, O_W2H + a1);
+            fm[slot] = lds_tr(lds, O_W2M + a0, O_W2M + a1);
+          };
+          if constexpr (mt == 0 && kb == 0) fetch(0, 0, 0, 0);
+          if constexpr (mt < 3) fetch(kb, mt + 1, Z, (mt + 1) & 1);
+          else if constexpr (kb + 1 < HK) fetch(kb + 1, 0, kb + 1 == 6, 0);
+          fl[(mt + 3) & 3] = lo_frag(C::S_L2T + 4 * kb + mt + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          step6<6 * mt>(accd[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+            if constexpr (kb + 1 < HK)
+              sfor<0, 2>([&](auto i) { dh2_item(ic<kb + 1>{}, ic<2 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
+          });
+        });
+      });
+    }
+    float logit = lgs[0] + lgs[1] + (g == 1 ? skipv : 0.0f);
+    logit += __shfl_xor(logit, 32);
+
+    // ================================================================ dh1 = accd * [a1 > 0], dh1[skip row] = 1; three levels
+    u32x4 dhl[HK][3];
+    sfor<0, HK>([&](auto kbc) {
+      constexpr int kb = decltype(kbc)::value, t = kb >> 1;
+      constexpr int nbits = (kb >> 2) == 0 ? 32 : 8 * (HK - 4);   // pushes into this mask word
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = 2 * p + h, k = 8 * (kb & 3) + e;
+          const unsigned bit = (unsigned)__builtin_amdgcn_sbfe((int)m1w[kb >> 2], nbits - 1 - k, 1);   // 0 or all ones
+          v[h] = __uint_as_float(__float_as_uint(accd[t][8 * (kb & 1) + e]) & bit);
+          if (kb == 6 && e == 0) v[h] = g == 1 ? 1.0f : v[h];   // position 100: d logit / d skip
+        }
+        split_pair(v[0], v[1], dhl[kb], p);
+      }
+    });
+
+    // ================================================================ L1^T: din = W1ext^T dh1, then the chain rule
+    float gxs[2] = {0.f, 0.f}, gys[2] = {0.f, 0.f}, gt = 0.f;
+    X32_OPAQUE2(t1);
+    {
+      u32x4 fl7[7];   // third level: ring of 7 = the steps of one output tile (three steps ahead)
+      fl7[0] = fl[0]; fl7[1] = fl[1]; fl7[2] = fl[2];
+      f32x16 accp, accc;
+      u32x4 fhn, fmn;   // hi / mid fragments of the next tile's first step
+      f32x4 tw[2][2];
+      EvalState es[2];
+      float de[2];
+      int ep_ft = 0;
+      auto ep_load = [&](int pr) __attribute__((always_inline)) {   // pair pr = registers 2 pr, 2 pr + 1
+        const int off = ep_ft + 128 * ((2 * pr) >> 2) + 16 * ((2 * pr) & 3);
+        tw[pr & 1][0] = lds128f(lds, off);
+        tw[pr & 1][1] = lds128f(lds, off + 16);
+      };
+      // chain-rule epilogue of the previous tile (plain positional features), 8 pairs x 22 instructions, 5 per slot
+      auto ep_item = [&](auto wc) __attribute__((always_inline)) {
+        constexpr int w = decltype(wc)::value;
+        if constexpr (w < 176) {
+          constexpr int pr = w / 22, u = w % 22, which = u & 1, st = u >> 1, r = 2 * pr + which;
+          if constexpr (u == 0 && pr < 7) ep_load(pr + 1);
+          if constexpr (st < 8) eval_item<st>(es[which], tw[pr & 1][which], ux, uy);
+          if constexpr (st == 8) de[which] = accp[r] * es[which].v;
+          if constexpr (st == 9) gxs[which] = fmaf(de[which], tw[pr & 1][which].x, gxs[which]);
+          if constexpr (st == 10) gys[which] = fmaf(de[which], tw[pr & 1][which].y, gys[which]);
+        }
+      };
+      auto l1t_tile = [&](auto hook_c, int mt, f32x16& acc) __attribute__((always_inline)) {
+        constexpr bool HOOK = decltype(hook_c)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        if constexpr (HOOK) { ep_ft = ftdl + 512 * (mt - 1); ep_load(0); }
+        auto fetch = [&](int kbn, int mtn, int zn, u32x4& oh, u32x4& om) __attribute__((always_inline)) {
+          const int a0 = t1[0][zn] + 64 * mtn + (zn ? 0 : 16 * RS1 * kbn);
+          const int a1 = t1[1][zn] + 64 * mtn + (zn ? 0 : 16 * RS1 * kbn);
+          oh = lds_tr(lds, O_W1H + a0, O_W1H + a1);
+          om = lds_tr(lds, O_W1M + a0, O_W1M + a1);
+        };
+        fh[0] = fhn; fm[0] = fmn;   // fetched during the previous tile's last step
+        sfor<0, HK>([&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value;
+          if constexpr (kb + 1 < HK) fetch(kb + 1, mt, kb + 1 == 6, fh[(kb + 1) & 1], fm[(kb + 1) & 1]);
+          else fetch(0, mt + 1, 0, fhn, fmn);   // past the last tile: a harmless in-image read
+          fl7[(kb + 3) % 7] = lo_frag(C::S_L1T + HK * mt + kb + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          step6<6 * kb>(acc, fh[kb & 1], fm[kb & 1], fl7[kb], dhl[kb], [&](auto slot) {
+            if constexpr (HOOK) sfor<0, 5>([&](auto i) { ep_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}); });
+          });
+        });
+      };
+      // epilogue of a tile that can hold angle / ones / pad positions: evaluated after its steps
+      auto ep_any = [&](int mt, const f32x16& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int off = 512 * mt + 128 * (r >> 2) + 16 * (r & 3);
+          const f32x4 e = lds128f(lds, ftdl + off);
+          const float isa = *reinterpret_cast<const float*>(lds + isl + (off >> 2));
+          float arg = fmaf(e.x, ux, fmaf(e.y, uy, e.z));
+          const float za = (th + e.z) * e.x;
+          arg = isa != 0.0f ? za : arg;
+          const float d = acc[r] * sin_halfturns_hw(arg, e.w);
+          gxs[r & 1] = fmaf(d, isa != 0.0f ? 0.0f : e.x, gxs[r & 1]);
+          gys[r & 1] = fmaf(d, e.y, gys[r & 1]);
+          gt = fmaf(d, isa != 0.0f ? e.x : 0.0f, gt);
+        }
+      };
+      {
+        const int a0 = t1[0][0], a1 = t1[1][0];
+        fhn = lds_tr(lds, O_W1H + a0, O_W1H + a1);
+        fmn = lds_tr(lds, O_W1M + a0, O_W1M + a1);
+      }
+      l1t_tile(std::false_type{}, 0, accp);
+#pragma unroll 1
+      for (int mt = 1; mt < C::NMT; ++mt) {
+        l1t_tile(std::true_type{}, mt, accc);
+        accp = accc;
+      }
+      ep_any(C::NMT - 1, accp);
+    }
+    float gx = gxs[0] + gxs[1], gy = gys[0] + gys[1];
+    gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gt += __shfl_xor(gt, 32);
+    if (a.out4 && g == 0 && pidx < a.n_points)
+      *reinterpret_cast<f32x4*>(a.out4 + pidx * 4) = f32x4{logit, gx / geo.sigma, gy / geo.sigma, gt};
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+// Image + blob per (device, stream): the prep kernel rewrites them on the launch stream in front of every launch (the
+// parameters may have changed), so launches of one stream are ordered by the stream itself.
+constexpr int MAX_SLOTS = 16;
+struct Slot { hipStream_t stream; void* ptr; size_t bytes; bool used; unsigned long long stamp; };
+static Slot g_slots[MAX_DEVICES][MAX_SLOTS] = {};
+static unsigned long long g_stamp = 0;
+static std::mutex g_mutex;
+
+static int buffers_for_stream(size_t bytes, hipStream_t stream, void** out) {
+  const int dev = current_device();
+  if (dev < 0) return NFOPP_ERR_HIP;
+  std::lock_guard<std::mutex> lock(g_mutex);
+  Slot* slot = nullptr;
+  for (int k = 0; k < MAX_SLOTS && !slot; ++k)
+    if (g_slots[dev][k].used && g_slots[dev][k].stream == stream) slot = &g_slots[dev][k];
+  for (int k = 0; k < MAX_SLOTS && !slot; ++k)
+    if (!g_slots[dev][k].used) { slot = &g_slots[dev][k]; slot->used = true; }
+  if (!slot) {   // every slot taken: reuse the least recently used one (its stream's launches are done or ordered before ours
+                 // only if it is idle, so wait for the device once; a 17th concurrent stream is not the realistic case)
+    slot = &g_slots[dev][0];
+    for (int k = 1; k < MAX_SLOTS; ++k)
+      if (g_slots[dev][k].stamp < slot->stamp) slot = &g_slots[dev][k];
+    NFOPP_HIP(hipDeviceSynchronize());
+  }
+  slot->stream = stream;
+  slot->stamp = ++g_stamp;
+  if (slot->bytes < bytes) {
+    if (slot->ptr) NFOPP_HIP(hipFree(slot->ptr));
+    slot->ptr = nullptr; slot->bytes = 0;
+    NFOPP_HIP(hipMalloc(&slot->ptr, bytes));
+    slot->bytes = bytes;
+  }
+  *out = slot->ptr;
+  return NFOPP_OK;
+}
+
+template <int NKB, int MODE>
+static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
+  using C = Cfg<NKB>;
+  static bool attr_set[MAX_DEVICES] = {};
+  auto kern = onf_x32_kernel<NKB, MODE>;
+  int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), IMG_BYTES, attr_set);
+  if (rc != NFOPP_OK) return rc;
+  void* buf = nullptr;
+  rc = buffers_for_stream(IMG_BYTES + C::BLOB_BYTES, stream, &buf);
+  if (rc != NFOPP_OK) return rc;
+  u32x4* img = reinterpret_cast<u32x4*>(buf);
+  u32x4* blob = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(buf) + IMG_BYTES);
+  constexpr int N_PIECES = IMG_BYTES / 16 + (C::STEPS + 4) * 64;
+  hipLaunchKernelGGL(x32_prep_kernel<NKB>, dim3((N_PIECES + 255) / 256), dim3(256), 0, stream, a.geom, a.params, img, blob);
+  NFOPP_HIP(hipGetLastError());
+  const long long n_chunks = (a.n_points + CH - 1) / CH;
+  long long grid = query_cus();
+  if (grid > n_chunks) grid = n_chunks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), IMG_BYTES, stream, a, (const u32x4*)img, (const u32x4*)blob);
+  NFOPP_HIP(hipGetLastError());
+  return NFOPP_OK;
+}
+
+}  // namespace x32
+
+// Feature dimensions the 32x32 kernel covers: one pad position must be free for the ones feature.
+bool onf_x32_supports(const OnfGeom& g) {
+  const int nkb = (g.fin + 16) >> 4;
+  return (g.n_enc == 200 && (nkb == 14 || nkb == 13)) || (g.n_enc == 100 && (nkb == 8 || nkb == 7));
+}
+
+int launch_onf_x32_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only) {
+  if (a.n_points <= 0) return NFOPP_OK;
+  const int nkb = (a.geom.fin + 16) >> 4;
+  switch (nkb) {
+    case 14: return forward_only ? x32::launch_t<14, 2>(a, stream) : x32::launch_t<14, 0>(a, stream);
+    case 13: return forward_only ? x32::launch_t<13, 2>(a, stream) : x32::launch_t<13, 0>(a, stream);
+    case 8: return forward_only ? x32::launch_t<8, 2>(a, stream) : x32::launch_t<8, 0>(a, stream);
+    case 7: return forward_only ? x32::launch_t<7, 2>(a, stream) : x32::launch_t<7, 0>(a, stream);
+    default:
+      set_error("unsupported ONF feature dimension %d", a.geom.fin);
+      return NFOPP_ERR_ARG;
+  }
+}
+
+}  // namespace nfopp
