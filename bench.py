@@ -177,7 +177,7 @@ def short_parity(onf, starts, goals, n, sample, steps, device):
            "p99_abs_traj": float(np.percentile(diff, 99)), "median_abs_traj": float(np.median(diff)),
            "oracle_seconds": cpu_s,
            "note": "same initial state, same Philox t stream; straight-line starts make single entries ill-conditioned "
-                   "under Adam (the reference restarted 1 ulp away moves by 2 lr = 0.1 in such entries, tests/conftest.py)"}
+                   "under Adam (the reference restarted 1 ulp away moves by 2 lr = 0.1 in such entries after ONE step: tools/ref_conditioning.py -> tests/golden/g17_conditioning.npz, batch_k1_max)"}
     for tag, k in (("first_step", 0), ("last_step", steps - 1)):
         rel = {}
         for ours, theirs in TERM_PAIRS:

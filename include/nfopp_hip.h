@@ -209,13 +209,15 @@ int nfopp_path_select_best(const float* labels_dev, const float* length_dev, con
                            float* best_length_dev, uint8_t* collides_dev, uint8_t* active_dev, void* stream);
 /* Matrix path of the fused ONF kernels (nfopp_onf_eval_points / _logits / nfopp_traj_collision_eval):
  *   1 (default) = bf16x3 split-precision MFMA: every fp32 operand is split EXACTLY into three bf16 levels and the six
- *       partial products above 2^-24 are accumulated in fp32 on the bf16 matrix pipe (csrc/onf_split.hip) -- fp32-faithful
- *       (closer to float64 than a sequential fp32 dot product), 1.5x faster than
- *   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/onf_fused.hip), which the ONF training pass always uses.
- *   The environment variable NFOPP_MATRIX_PATH=fp32 selects 0 at load time.  Process-wide.
- *   Path 1 keeps ONE scratch buffer per device (the third weight level, 164 KB, rebuilt from params_dev by a 5 us
- *   kernel in front of every evaluation on the caller's stream): evaluations of DIFFERENT parameter sets must not run
- *   concurrently on different streams of one device. */
+ *       partial products above 2^-24 are accumulated in fp32 on the bf16 matrix pipe -- fp32-faithful (closer to float64
+ *       than a sequential fp32 dot product).  Launches that give every CU a full 256-sample chunk run on 32x32x16 tiles
+ *       (csrc/onf_x32.hip), smaller ones and the training pass on 16x16x32 tiles (csrc/onf_split.hip).
+ *   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/onf_fused.hip).
+ *   2 = bf16x3 split, the 16x16x32 kernel at every size;  3 = bf16x3 split, the 32x32x16 kernel at every size.
+ *   The environment variable NFOPP_MATRIX_PATH=fp32|0|1|2|3 selects the path at load time.  Process-wide.
+ *   The split paths keep ONE scratch image per (device, stream) (pre-split weights, rebuilt from params_dev by a small
+ *   kernel in front of every evaluation on the caller's stream), at most 16 per device: a 17th stream reuses the least
+ *   recently used slot after a device synchronisation. */
 int nfopp_set_matrix_path(int32_t path);
 int nfopp_get_matrix_path(void);
 

@@ -171,19 +171,31 @@ __device__ __forceinline__ long long work_points(const OnfKernelArgs& a) {
   return a.live ? (long long)a.live[0] * (a.n_way - 1) : a.n_points;
 }
 
-// Pose of work item p (padding lanes past n_work repeat the last item).  Returns the row its outputs belong to --
-// a.n_points for a padding lane, so `row < a.n_points` is the store predicate.  Trajectory mode draws / reads the
-// interpolation parameter and forms the collision sample: constrained:78-81 (SE(2)) / nerf:113-117 (2-D).
-__device__ __forceinline__ long long load_point(const OnfKernelArgs& a, long long n_work, long long p, int g, float& x,
-                                                float& y, float& ang) {
-  const bool valid = p < n_work;
-  if (!valid) p = n_work - 1;
-  ang = 0.f;
+// Pose of work item p (padding lanes past n_work repeat the last item), in two halves so that a persistent kernel can
+// issue the loads of its NEXT chunk early: point_fetch issues the global loads and point_finish does the arithmetic.
+// load_point = both.  Returns the row the item's outputs belong to -- a.n_points for a padding lane, so
+// `row < a.n_points` is the store predicate.  Trajectory mode draws / reads the interpolation parameter and forms the
+// collision sample: constrained:78-81 (SE(2)) / nerf:113-117 (2-D).
+struct RawPoint {
+  float qa[3], qb[3];       // explicit mode: qa = the pose;  trajectory mode: traj[:-1][j], traj[1:][j]
+  float t;                  // t_mode 0: the injected draw
+  long long row;            // output row, a.n_points for a padding lane
+  unsigned long long gp;    // global sample index (Philox counter)
+  bool valid;
+};
+
+__device__ __forceinline__ void point_fetch(const OnfKernelArgs& a, long long n_work, long long p, RawPoint& r) {
+  r.valid = p < n_work;
+  if (!r.valid) p = n_work - 1;
+  r.qa[2] = r.qb[0] = r.qb[1] = r.qb[2] = 0.f;
+  r.t = 0.f;
+  r.gp = 0;
   if (a.points) {
     const float* q = a.points + p * a.geom.point_dim;
-    x = q[0]; y = q[1];
-    if (a.geom.point_dim == 3) ang = q[2];
-    return valid ? p : a.n_points;
+    r.qa[0] = q[0]; r.qa[1] = q[1];
+    if (a.geom.point_dim == 3) r.qa[2] = q[2];
+    r.row = r.valid ? p : a.n_points;
+    return;
   }
   const int nseg = a.n_way - 1;
   long long b;
@@ -198,28 +210,47 @@ __device__ __forceinline__ long long load_point(const OnfKernelArgs& a, long lon
   }
   if (a.live) b = a.live[1 + b];
   const long long row = b * nseg + j;
-  float tt;
-  if (a.t_mode == 0) {
-    tt = a.t[row];
-  } else {
-    unsigned long long gp = (unsigned long long)((a.traj_index_offset + b) * nseg + j);
-    tt = philox_uniform(a.seed, gp, a.rng_offset);
-    if (g == 0 && valid) a.t[row] = tt;
-  }
+  if (a.t_mode == 0) r.t = a.t[row];
+  else r.gp = (unsigned long long)((a.traj_index_offset + b) * nseg + j);
   const float* qa = a.traj + (b * a.n_way + j) * a.dim;  // traj[:-1]
   const float* qb = qa + a.dim;                           // traj[1:]
+  r.qa[0] = qa[0]; r.qa[1] = qa[1]; r.qb[0] = qb[0]; r.qb[1] = qb[1];
+  if (a.dim == 3) { r.qa[2] = qa[2]; r.qb[2] = qb[2]; }
+  r.row = row;
+}
+
+__device__ __forceinline__ long long point_finish(const OnfKernelArgs& a, const RawPoint& r, int g, float& x, float& y,
+                                                   float& ang) {
+  ang = 0.f;
+  if (a.points) {
+    x = r.qa[0]; y = r.qa[1];
+    if (a.geom.point_dim == 3) ang = r.qa[2];
+    return r.row;
+  }
+  float tt = r.t;
+  if (a.t_mode != 0) {
+    tt = philox_uniform(a.seed, r.gp, a.rng_offset);
+    if (g == 0 && r.valid) a.t[r.row] = tt;
+  }
   // every product and sum rounded on its own, as the reference's separate torch ops do (no fused multiply-add): the
   // sample is then bit-identical to the oracle's for the same t, and K1 sees the reference's inputs
   if (a.dim == 3) {
     // constrained:79-81  p = traj[1:] + t * wrap-theta(traj[:-1] - traj[1:])
-    float dx = qa[0] - qb[0], dy = qa[1] - qb[1], dth = wrap_angle(qa[2] - qb[2]);
-    x = add_mul_unfused(qb[0], tt, dx); y = add_mul_unfused(qb[1], tt, dy); ang = add_mul_unfused(qb[2], tt, dth);
+    float dx = r.qa[0] - r.qb[0], dy = r.qa[1] - r.qb[1], dth = wrap_angle(r.qa[2] - r.qb[2]);
+    x = add_mul_unfused(r.qb[0], tt, dx); y = add_mul_unfused(r.qb[1], tt, dy); ang = add_mul_unfused(r.qb[2], tt, dth);
   } else {
     // nerf:117  p = traj[1:] * (1 - t) + traj[:-1] * t
     float omt = 1.0f - tt;
-    x = mix_unfused(qb[0], omt, qa[0], tt); y = mix_unfused(qb[1], omt, qa[1], tt);
+    x = mix_unfused(r.qb[0], omt, r.qa[0], tt); y = mix_unfused(r.qb[1], omt, r.qa[1], tt);
   }
-  return valid ? row : a.n_points;
+  return r.valid ? r.row : a.n_points;
+}
+
+__device__ __forceinline__ long long load_point(const OnfKernelArgs& a, long long n_work, long long p, int g, float& x,
+                                                float& y, float& ang) {
+  RawPoint r;
+  point_fetch(a, n_work, p, r);
+  return point_finish(a, r, g, x, y, ang);
 }
 
 }  // namespace nfopp

@@ -1034,34 +1034,30 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void onf_split_kernel(const
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-// -1: read NFOPP_MATRIX_PATH on first use; 0: fp32 MFMA; 1: bf16x3 split (default: the 32x32x16 kernel of csrc/onf_x32.hip
-// for launches that give every CU a full chunk, this file's 16x16x32 kernel for small launches and the training pass);
-// 2: bf16x3 split, this file's kernel at every size; 3: bf16x3 split, the 32x32x16 kernel at every size (tests)
+// -1: read NFOPP_MATRIX_PATH on first use; 0: fp32 MFMA; 1: bf16x3 split (default): the 32x32x16 kernel of csrc/onf_x32.hip
+// at EVERY launch size -- results must not depend on how a batch is sharded -- and this file's 16x16x32 kernel for the
+// training pass and the feature dimensions the other does not cover; 2: bf16x3 split, this file's kernel everywhere
 static int g_split_mode = -1;
 
 static int split_mode() {
   if (g_split_mode < 0) {
     const char* e = getenv("NFOPP_MATRIX_PATH");
-    g_split_mode = !e ? 1 : (e[0] == 'f' || e[0] == '0') ? 0 : (e[0] == '2' || e[0] == 's') ? 2 : (e[0] == '3' || e[0] == 'x') ? 3 : 1;
+    g_split_mode = !e ? 1 : (e[0] == 'f' || e[0] == '0') ? 0 : e[0] == '2' ? 2 : 1;
   }
   return g_split_mode;
 }
 
 bool onf_split_enabled() { return split_mode() >= 1; }
 
-// the 32x32x16 kernel takes the launch when it covers the feature dimension and the launch fills the chip
-bool onf_use_x32(const OnfGeom& g, long long n_points) {
-  const int m = split_mode();
-  if (m != 1 && m != 3) return false;
-  if (!onf_x32_supports(g)) return false;
-  return m == 3 || n_points >= (long long)query_cus() * 256;
-}
+// the 32x32x16 kernel takes the launch whenever it covers the feature dimension
+bool onf_use_x32(const OnfGeom& g) { return split_mode() == 1 && onf_x32_supports(g); }
 
 // Third-level blobs.  split_prep_kernel rewrites the blob in front of every launch ON THE LAUNCH STREAM, so launches of
 // one stream are ordered by the stream itself; two streams of one device (two planners with different fields) must not
 // share a blob, so blobs are keyed by (device, stream).  A handful of streams per device is the realistic case.
 constexpr int MAX_BLOBS = 16;
-struct BlobSlot { hipStream_t stream; void* ptr; size_t bytes; bool used; };
+struct BlobSlot { hipStream_t stream; void* ptr; size_t bytes; bool used; unsigned long long stamp; };
+static unsigned long long g_blob_stamp = 0;
 static BlobSlot g_blobs[MAX_DEVICES][MAX_BLOBS] = {};
 static std::mutex g_blob_mutex;
 
@@ -1073,8 +1069,16 @@ static int blob_for_stream(size_t bytes, hipStream_t stream, u32x4** out) {
   for (int k = 0; k < MAX_BLOBS && !slot; ++k)
     if (g_blobs[dev][k].used && g_blobs[dev][k].stream == stream) slot = &g_blobs[dev][k];
   for (int k = 0; k < MAX_BLOBS && !slot; ++k)
-    if (!g_blobs[dev][k].used) { slot = &g_blobs[dev][k]; slot->used = true; slot->stream = stream; }
-  NFOPP_REQUIRE(slot, "more than %d streams launch the split-path ONF kernel on device %d", MAX_BLOBS, dev);
+    if (!g_blobs[dev][k].used) { slot = &g_blobs[dev][k]; slot->used = true; }
+  if (!slot) {   // every slot taken (PyTorch's pool alone hands out 32 streams per priority): reuse the least recently used one;
+                 // its stream may still be running on the blob, so wait for the device once
+    slot = &g_blobs[dev][0];
+    for (int k = 1; k < MAX_BLOBS; ++k)
+      if (g_blobs[dev][k].stamp < slot->stamp) slot = &g_blobs[dev][k];
+    NFOPP_HIP(hipDeviceSynchronize());
+  }
+  slot->stream = stream;
+  slot->stamp = ++g_blob_stamp;
   if (slot->bytes < bytes) {
     if (slot->ptr) NFOPP_HIP(hipFree(slot->ptr));
     slot->ptr = nullptr; slot->bytes = 0;
@@ -1175,7 +1179,7 @@ int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, in
 
 int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only) {
   if (a.n_points <= 0) return NFOPP_OK;
-  if (onf_use_x32(a.geom, a.n_points)) return launch_onf_x32_kernel(a, stream, forward_only);
+  if (onf_use_x32(a.geom)) return launch_onf_x32_kernel(a, stream, forward_only);
   return forward_only ? launch_split_mode<2>(a, stream) : launch_split_mode<0>(a, stream);
 }
 
@@ -1184,9 +1188,8 @@ int launch_onf_split_kernel(const OnfKernelArgs& a, hipStream_t stream, bool for
 using namespace nfopp;
 
 extern "C" int nfopp_set_matrix_path(int32_t path) {
-  NFOPP_REQUIRE(path >= 0 && path <= 3,
-                "matrix path must be 0 (fp32 MFMA), 1 (bf16x3 split MFMA), 2 (split, 16x16x32 kernel only) or 3 (split, 32x32x16 "
-                "kernel at every size)");
+  NFOPP_REQUIRE(path >= 0 && path <= 2,
+                "matrix path must be 0 (fp32 MFMA), 1 (bf16x3 split MFMA) or 2 (bf16x3 split MFMA, 16x16x32 kernels only)");
   g_split_mode = path;
   return NFOPP_OK;
 }

@@ -907,9 +907,9 @@ static WgradWs carve_wgrad(const OnfGeom& g, long long P) {
   w.dh1 = o; o += P * HS;
   w.de = o; o += P * w.win;
   w.rec = o; o += P * 12;
-  w.loss = o; o += (long long)w.grid_cap * 8;
+  w.loss = o; o += (long long)w.grid_cap * WAVES;   // pass 1 writes one row per wave
   w.loss_sum = o; o += 4;
-  w.g4_partial = o; o += (long long)w.grid_cap * 8 * HS;
+  w.g4_partial = o; o += (long long)w.grid_cap * WAVES * HS;
   w.g4 = o; o += HS;
   w.partial = o; o += (long long)w.grid_cap * w.ntiles * 256;
   w.reduced = o; o += (long long)w.ntiles * 256;
@@ -979,9 +979,9 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
                      ws + w.reduced, n_elems, grid);
   NFOPP_HIP(hipGetLastError());
   // loss and dW3[:100]: per-wave partials of pass 1
-  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.loss, ws + w.loss_sum, 1, grid_fwd * 8);
+  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.loss, ws + w.loss_sum, 1, grid_fwd * WAVES);
   NFOPP_HIP(hipGetLastError());
-  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(HS), dim3(256), 0, st, ws + w.g4_partial, ws + w.g4, HS, grid_fwd * 8);
+  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(HS), dim3(256), 0, st, ws + w.g4_partial, ws + w.g4, HS, grid_fwd * WAVES);
   NFOPP_HIP(hipGetLastError());
   GatherArgs ga;
   ga.geom = g; ga.nkt = nkt; ga.aug_in_slot = slot_layout_p(aug);   ga.params = params; ga.reduced = ws + w.reduced; ga.g4 = ws + w.g4; ga.loss_partial = ws + w.loss_sum; ga.grad = grad; ga.count = (float)P;

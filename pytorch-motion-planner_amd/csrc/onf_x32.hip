@@ -210,10 +210,17 @@ __device__ __forceinline__ u32x4 lds_tr(const unsigned char* lds, int byte0, int
 }
 
 // 6 partial products of one step (smallest terms first); WORK(slot) runs behind MFMA number slot - SLOT0
-template <int SLOT0, class W>
+// FIRST: the accumulator starts here -- the first product takes a literal zero as its C operand (no register zeroing)
+template <int SLOT0, bool FIRST = false, class W>
 __device__ __forceinline__ void step6(f32x16& acc, const u32x4& ah, const u32x4& am, const u32x4& al, const u32x4 (&b)[3],
                                       W&& work) {
-  acc = mfma32(al, b[0], acc); work(ic<SLOT0 + 0>{}); __builtin_amdgcn_sched_barrier(0);
+  if constexpr (FIRST) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc = mfma32(al, b[0], zero);
+  } else {
+    acc = mfma32(al, b[0], acc);
+  }
+  work(ic<SLOT0 + 0>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(ah, b[2], acc); work(ic<SLOT0 + 1>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(am, b[1], acc); work(ic<SLOT0 + 2>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(am, b[0], acc); work(ic<SLOT0 + 3>{}); __builtin_amdgcn_sched_barrier(0);
@@ -258,6 +265,19 @@ __device__ __forceinline__ void eval_item(EvalState& s, const f32x4& tw, float u
 
 constexpr int CH = 8 * 32;   // samples per workgroup pass: 8 waves x one 32-sample tile
 
+// Development build (make EXTRA=-DX32_PHASE_PROFILE): waves 0 and 4 of every workgroup accumulate clock ticks per phase of the
+// chunk loop; launch_t prints the shares every tenth launch of the mode-0 kernel (synchronous, stderr).
+#ifdef X32_PHASE_PROFILE
+#define X32_TICK(SLOT)                                             \
+  {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();  \
+    phase_ticks[SLOT] += (float)(now_ - phase_t0);                 \
+    phase_t0 = now_;                                               \
+  }
+#else
+#define X32_TICK(SLOT)
+#endif
+
 template <int NKB, int MODE>
 __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, const u32x4* __restrict__ img,
                                                          const u32x4* __restrict__ blob) {
@@ -277,36 +297,47 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
   __syncthreads();
   // static priority for the younger half (MI355X_MICROARCH.md); the condition must be provably wave-uniform, or hipcc
   // lowers it to an exec mask around an UNCONDITIONAL s_setprio
+#ifndef X32_NO_PRIO
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 
   const OnfGeom& geo = a.geom;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
   // ---- lane parts of every LDS address (formulas: tools/x32/emulate_x32.py) ----
-  const int xs = (j >> 2) & 3;
-  const int lowE = 16 * ((g ^ xs) & 3), lowO = 16 * (((2 | g) ^ xs) & 3);
-  const int row31 = min(96 + j, W1_ZERO), row32 = min(96 + j, W2_ZERO);
-  // forward W1: + 64 (kb >> 1) + 32 * RS1 * mt; [parity of kb][tile 3 ?]
-  int w1f[2][2] = {{j * RS1 + lowE, row31 * RS1 + lowE}, {j * RS1 + lowO, row31 * RS1 + lowO}};
-  // forward W2: (base ^ (kb << 5)) + 32 * RS2 * mt
-  const int sw2 = 16 * swz2(j);
-  int w2f[2] = {(j * RS2 + sw2) ^ (g << 4), (row32 * RS2 + sw2) ^ (g << 4)};
   // Left to itself hipcc forms every (lane base + image offset + tile offset) once, in front of the persistent loop --
-  // some 200 registers -- and spills them; an empty asm at the start of each GEMM makes the few lane bases opaque so
-  // that the sums are formed where they are used (the same device as onf_split.hip's NFOPP_REDERIVE).
+  // some 200 registers -- and spills them.  So each GEMM derives its few bases from an OPAQUE copy of the lane index where
+  // it starts (a dozen integer instructions; the same device as onf_split.hip's NFOPP_REDERIVE), and nothing but the lane
+  // index itself stays live across the chunk.
+  int lane_v = lane;
 #define X32_OPAQUE2(A) asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]))
-  // transposed reads: lane = (g, a, q, p)
-  const int ta = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
-  int t2[2][2], t1[2][2];   // [eh][kb == 6 ?]
+  // forward W1: + 64 (kb >> 1) + 32 * RS1 * mt; [parity of kb][tile 3 ?]
+  auto bases_w1f = [&](int (&w1f)[2][2]) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(lane_v));
+    const int jj = lane_v & 31, gg = lane_v >> 5, xs = (jj >> 2) & 3;
+    const int lowE = 16 * ((gg ^ xs) & 3), lowO = 16 * (((2 | gg) ^ xs) & 3), row31 = min(96 + jj, W1_ZERO);
+    w1f[0][0] = jj * RS1 + lowE; w1f[0][1] = row31 * RS1 + lowE; w1f[1][0] = jj * RS1 + lowO; w1f[1][1] = row31 * RS1 + lowO;
+  };
+  // forward W2: (base ^ (kb << 5)) + 32 * RS2 * mt; [tile 3 ?]
+  auto bases_w2f = [&](int (&w2f)[2]) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(lane_v));
+    const int jj = lane_v & 31, gg = lane_v >> 5, sw2 = 16 * swz2(jj), row32 = min(96 + jj, W2_ZERO);
+    w2f[0] = (jj * RS2 + sw2) ^ (gg << 4); w2f[1] = (row32 * RS2 + sw2) ^ (gg << 4);
+  };
+  // transposed reads: lane = (g, a, q, p); [eh][kb == 6 ?]
+  //   W2: (base ^ (mt << 6)) + 16 * RS2 * kb;   W1: base + 16 * RS1 * kb + 64 * mt
+  auto bases_tr = [&](auto w1_c, int (&t)[2][2]) __attribute__((always_inline)) {
+    constexpr bool W1 = decltype(w1_c)::value;
+    asm volatile("" : "+v"(lane_v));
+    const int gg = lane_v >> 5, ta = (lane_v >> 4) & 1, tq = (lane_v >> 2) & 3, tp = lane_v & 3;
 #pragma unroll
-  for (int eh = 0; eh < 2; ++eh) {
-    const int low = 16 * (((2 * ta + (tp & 1)) ^ (2 * eh + g)) & 3) + 8 * (tp >> 1);
-    const int r = 8 * eh + 4 * g + tq;
-    t2[eh][0] = r * RS2 + 64 * tq + low;                          // (^ (mt << 6)) + 16 * RS2 * kb
-    t2[eh][1] = min(96 + r, W2_ZERO) * RS2 + 64 * tq + low;
-    t1[eh][0] = r * RS1 + low;                                    // + 16 * RS1 * kb + 64 * mt
-    t1[eh][1] = min(96 + r, W1_ZERO) * RS1 + low;
-  }
+    for (int eh = 0; eh < 2; ++eh) {
+      const int low = 16 * (((2 * ta + (tp & 1)) ^ (2 * eh + gg)) & 3) + 8 * (tp >> 1);
+      const int r = 8 * eh + 4 * gg + tq;
+      if (W1) { t[eh][0] = r * RS1 + low; t[eh][1] = min(96 + r, W1_ZERO) * RS1 + low; }
+      else { t[eh][0] = r * RS2 + 64 * tq + low; t[eh][1] = min(96 + r, W2_ZERO) * RS2 + 64 * tq + low; }
+    }
+  };
   int ftl = O_FT + 64 * g, ftdl = O_FTD + 64 * g, isl = O_ISA + 16 * g, w3al = O_W3A + 16 * g, w3ll = O_W3L + 48 * g;
   int fin_rel = geo.fin - 4 * g;   // position == fin  <=>  16 kb + 8 (e >> 2) + (e & 3) == fin_rel
 
@@ -320,6 +351,19 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
   const long long n_work = work_points(a);
   const long long n_chunks = (n_work + CH - 1) / CH;
 
+#ifdef X32_PHASE_PROFILE
+  float phase_ticks[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned long long phase_t0 = __builtin_readcyclecounter();
+#endif
+  // The loads of a chunk's samples (and the first three third-level fragments) are issued during the PREVIOUS chunk's
+  // last GEMM, so that no chunk starts by waiting for global memory.
+  if (n_chunks <= (long long)blockIdx.x) return;   // (an empty live list: nothing to do, and no sample to prefetch)
+  RawPoint raw;
+  point_fetch(a, n_work, (long long)blockIdx.x * CH + wave * 32 + j, raw);
+  // third-level fragments: ring of 4, three steps ahead, running on across the GEMMs (blob steps are consecutive) and,
+  // at the end of a chunk, on into the first steps of the next
+  u32x4 fl[4];
+  fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     float ux, uy, th;
     long long pidx;
@@ -328,14 +372,11 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
     asm volatile("" : "+v"(ftl), "+v"(ftdl), "+v"(isl), "+v"(w3al), "+v"(w3ll), "+v"(fin_rel));
     {
       float x, y, ang;
-      pidx = load_point(a, n_work, chunk * CH + wave * 32 + j, g, x, y, ang);
+      pidx = point_finish(a, raw, g, x, y, ang);
       ux = (x - geo.mean) / geo.sigma;
       uy = (y - geo.mean) / geo.sigma;
       th = ang;
     }
-    // third-level fragments: ring of 4, three steps ahead, running on across the GEMMs (blob steps are consecutive)
-    u32x4 fl[4];
-    fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
     u32x4 fh[2], fm[2];   // hi / mid fragments: this step and the next
 
     // generic evaluation of one input feature (any kind), used for the first block and the angle / ones / pad blocks
@@ -358,6 +399,7 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
       for (int p = 0; p < 4; ++p) split_pair(feature_any(special_c, kb, 2 * p), feature_any(special_c, kb, 2 * p + 1), out, p);
     };
 
+    X32_TICK(0)   // sampling
     // ================================================================ L1: a1 = W1ext in
     f32x16 acc1[4];
 #pragma unroll
@@ -365,6 +407,11 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
     {
+      int w1f[2][2];
+      bases_w1f(w1f);
+      // (the mid image's offset plus a tile offset does not fit the 16-bit immediate of an LDS read: its own bases)
+      int w1m[2][2] = {{w1f[0][0] + O_W1M, w1f[0][1] + O_W1M}, {w1f[1][0] + O_W1M, w1f[1][1] + O_W1M}};
+      X32_OPAQUE2(w1m);
       u32x4 bA[3], bB[3];
       features_upfront(std::false_type{}, 0, bA);
       // hooked preparation of the NEXT block's fragments: 4 pairs x (16 evaluation + 11 split) instructions, 5 per slot.
@@ -406,11 +453,12 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
           // this step's hi / mid were fetched one step ago; fetch the next step's (past the last block: a harmless
           // in-image read)
           if constexpr (mt < 3) {
-            const int ad = w1f[PAR][mt + 1 == 3] + kq + (mt + 1 < 3 ? 32 * RS1 * (mt + 1) : 0);
-            fh[(mt + 1) & 1] = lds128(lds, O_W1H + ad); fm[(mt + 1) & 1] = lds128(lds, O_W1M + ad);
+            const int off = kq + (mt + 1 < 3 ? 32 * RS1 * (mt + 1) : 0);
+            fh[(mt + 1) & 1] = lds128(lds, O_W1H + w1f[PAR][mt + 1 == 3] + off);
+            fm[(mt + 1) & 1] = lds128(lds, w1m[PAR][mt + 1 == 3] + off);
           } else {
-            const int ad = w1f[PAR ^ 1][0] + 64 * ((kb + 1) >> 1);
-            fh[0] = lds128(lds, O_W1H + ad); fm[0] = lds128(lds, O_W1M + ad);
+            const int off = 64 * ((kb + 1) >> 1);
+            fh[0] = lds128(lds, O_W1H + w1f[PAR ^ 1][0] + off); fm[0] = lds128(lds, w1m[PAR ^ 1][0] + off);
           }
           fl[(mt + 3) & 3] = lo_frag(C::S_L1 + 4 * kb + mt + 3);
           __builtin_amdgcn_sched_barrier(0);
@@ -420,8 +468,7 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
         });
       };
       constexpr int FS = C::FS;
-      X32_OPAQUE2(w1f);
-      fh[0] = lds128(lds, O_W1H + w1f[0][0]); fm[0] = lds128(lds, O_W1M + w1f[0][0]);
+      fh[0] = lds128(lds, O_W1H + w1f[0][0]); fm[0] = lds128(lds, w1m[0][0]);
 #pragma unroll 1
       for (int kp = 0; kp < FS / 2 - 1; ++kp) {
         l1_block(std::true_type{}, ic<0>{}, 2 * kp, bA, bB);
@@ -436,16 +483,14 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
         l1_block(std::false_type{}, ic<(kb & 1)>{}, kb, bA, bB);
       });
     }
+    X32_TICK(1)   // L1
     const float skipv = acc1[3][0];   // position 100 = tile 3, g = 1, register 0: W3b . in + b3 (lanes g = 1)
 
     // ================================================================ L2: a2 = W2ext relu(a1)
     f32x16 acc2[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
     unsigned m1w[2] = {0u, 0u};   // [a1 > 0]: block kb, element e -> word kb >> 2, pushed from the low end in order
-    asm volatile("" : "+v"(w2f[0]), "+v"(w2f[1]));
+    int w2f[2];
+    bases_w2f(w2f);
     {
       u32x4 bb[2][3];
       float hv[2];
@@ -480,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
           }
           fl[(mt + 3) & 3] = lo_frag(C::S_L2 + 4 * kb + mt + 3);
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * mt>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+          step6<6 * mt, kb == 0>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, 3>([&](auto i) { h1_item(ic<kb + 1>{}, ic<3 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
@@ -488,31 +533,29 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
       });
     }
 
+    X32_TICK(2)   // L2
     if constexpr (FWD_ONLY) {
-      float lg = 0.0f;
-      sfor<0, 4>([&](auto mtc) {
-        constexpr int mt = decltype(mtc)::value;
+      // the summation order of the full kernel (two chains over the element parity, blocks in order): same logits bit for bit
+      float lgs[2] = {0.0f, 0.0f};
+      sfor<0, HK>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        const f32x4 w3f[2] = {lds128f(lds, w3al + 64 * kb), lds128f(lds, w3al + 64 * kb + 32)};
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const f32x4 w3a = lds128f(lds, w3al + 128 * mt + 32 * q4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lg = fmaf(w3a[r], relu1(acc2[mt][4 * q4 + r]), lg);
-        }
+        for (int e = 0; e < 8; ++e) lgs[e & 1] = fmaf(w3f[e >> 2][e & 3], relu1(acc2[kb >> 1][8 * (kb & 1) + e]), lgs[e & 1]);
       });
-      lg += g == 1 ? skipv : 0.0f;
+      float lg = lgs[0] + lgs[1] + (g == 1 ? skipv : 0.0f);
       lg += __shfl_xor(lg, 32);
       if (g == 0 && pidx < a.n_points) *reinterpret_cast<f32x4*>(a.out4 + pidx * 4) = f32x4{lg, 0.f, 0.f, 0.f};
+      point_fetch(a, n_work, (chunk + gridDim.x) * CH + wave * 32 + j, raw);
+      fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
       continue;
     }
 
     // ================================================================ L2^T: W2ext^T dh2,  dh2 = W3a [a2 > 0]; the logit on the way
     f32x16 accd[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accd[mt][r] = 0.0f;
     float lgs[2] = {0.0f, 0.0f};
-    X32_OPAQUE2(t2);
+    int t2[2][2];
+    bases_tr(std::false_type{}, t2);
     {
       u32x4 bb[2][3];
       f32x4 w3f[2];     // fp32 W3a of the block's 8 positions
@@ -561,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
           else if constexpr (kb + 1 < HK) fetch(kb + 1, 0, kb + 1 == 6, 0);
           fl[(mt + 3) & 3] = lo_frag(C::S_L2T + 4 * kb + mt + 3);
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * mt>(accd[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+          step6<6 * mt, kb == 0>(accd[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, 2>([&](auto i) { dh2_item(ic<kb + 1>{}, ic<2 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
@@ -570,6 +613,7 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
     }
     float logit = lgs[0] + lgs[1] + (g == 1 ? skipv : 0.0f);
     logit += __shfl_xor(logit, 32);
+    X32_TICK(3)   // L2^T
 
     // ================================================================ dh1 = accd * [a1 > 0], dh1[skip row] = 1; three levels
     u32x4 dhl[HK][3];
@@ -590,9 +634,13 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
       }
     });
 
+    X32_TICK(4)   // dh1
     // ================================================================ L1^T: din = W1ext^T dh1, then the chain rule
     float gxs[2] = {0.f, 0.f}, gys[2] = {0.f, 0.f}, gt = 0.f;
-    X32_OPAQUE2(t1);
+    int t1[2][2];
+    bases_tr(std::true_type{}, t1);
+    int t1m[2][2] = {{t1[0][0] + O_W1M, t1[0][1] + O_W1M}, {t1[1][0] + O_W1M, t1[1][1] + O_W1M}};
+    X32_OPAQUE2(t1m);
     {
       u32x4 fl7[7];   // third level: ring of 7 = the steps of one output tile (three steps ahead)
       fl7[0] = fl[0]; fl7[1] = fl[1]; fl7[2] = fl[2];
@@ -621,23 +669,23 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
       };
       auto l1t_tile = [&](auto hook_c, int mt, f32x16& acc) __attribute__((always_inline)) {
         constexpr bool HOOK = decltype(hook_c)::value;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         if constexpr (HOOK) { ep_ft = ftdl + 512 * (mt - 1); ep_load(0); }
         auto fetch = [&](int kbn, int mtn, int zn, u32x4& oh, u32x4& om) __attribute__((always_inline)) {
-          const int a0 = t1[0][zn] + 64 * mtn + (zn ? 0 : 16 * RS1 * kbn);
-          const int a1 = t1[1][zn] + 64 * mtn + (zn ? 0 : 16 * RS1 * kbn);
-          oh = lds_tr(lds, O_W1H + a0, O_W1H + a1);
-          om = lds_tr(lds, O_W1M + a0, O_W1M + a1);
+          const int off = 64 * mtn + (zn ? 0 : 16 * RS1 * kbn);
+          oh = lds_tr(lds, O_W1H + t1[0][zn] + off, O_W1H + t1[1][zn] + off);
+          om = lds_tr(lds, t1m[0][zn] + off, t1m[1][zn] + off);
         };
         fh[0] = fhn; fm[0] = fmn;   // fetched during the previous tile's last step
         sfor<0, HK>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value;
           if constexpr (kb + 1 < HK) fetch(kb + 1, mt, kb + 1 == 6, fh[(kb + 1) & 1], fm[(kb + 1) & 1]);
           else fetch(0, mt + 1, 0, fhn, fmn);   // past the last tile: a harmless in-image read
-          fl7[(kb + 3) % 7] = lo_frag(C::S_L1T + HK * mt + kb + 3);
+          {   // past the last step of the chunk: the next chunk's first steps
+            const int st = C::S_L1T + HK * mt + kb + 3;
+            fl7[(kb + 3) % 7] = lo_frag(st >= C::STEPS ? st - C::STEPS : st);
+          }
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * kb>(acc, fh[kb & 1], fm[kb & 1], fl7[kb], dhl[kb], [&](auto slot) {
+          step6<6 * kb, kb == 0>(acc, fh[kb & 1], fm[kb & 1], fl7[kb], dhl[kb], [&](auto slot) {
             if constexpr (HOOK) sfor<0, 5>([&](auto i) { ep_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}); });
           });
         });
@@ -659,23 +707,31 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
         }
       };
       {
-        const int a0 = t1[0][0], a1 = t1[1][0];
-        fhn = lds_tr(lds, O_W1H + a0, O_W1H + a1);
-        fmn = lds_tr(lds, O_W1M + a0, O_W1M + a1);
+        fhn = lds_tr(lds, O_W1H + t1[0][0], O_W1H + t1[1][0]);
+        fmn = lds_tr(lds, t1m[0][0], t1m[1][0]);
       }
+      point_fetch(a, n_work, (chunk + gridDim.x) * CH + wave * 32 + j, raw);   // next chunk's samples (finished at its start)
+      __builtin_amdgcn_sched_barrier(0);
       l1t_tile(std::false_type{}, 0, accp);
 #pragma unroll 1
       for (int mt = 1; mt < C::NMT; ++mt) {
         l1t_tile(std::true_type{}, mt, accc);
         accp = accc;
       }
+      X32_TICK(5)   // L1^T steps + hooked epilogues
       ep_any(C::NMT - 1, accp);
+      fl[0] = fl7[0]; fl[1] = fl7[1]; fl[2] = fl7[2];   // steps 0..2 of the next chunk (fetched during the last tile)
     }
     float gx = gxs[0] + gxs[1], gy = gys[0] + gys[1];
     gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gt += __shfl_xor(gt, 32);
     if (a.out4 && g == 0 && pidx < a.n_points)
       *reinterpret_cast<f32x4*>(a.out4 + pidx * 4) = f32x4{logit, gx / geo.sigma, gy / geo.sigma, gt};
+    X32_TICK(6)   // last epilogue + output
   }
+#ifdef X32_PHASE_PROFILE
+  if (MODE == 0 && a.ws_u && (threadIdx.x == 0 || threadIdx.x == 256))
+    for (int k = 0; k < 8; ++k) atomicAdd(a.ws_u + k + (threadIdx.x ? 8 : 0), phase_ticks[k]);
+#endif
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -733,6 +789,30 @@ static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
   const long long n_chunks = (a.n_points + CH - 1) / CH;
   long long grid = query_cus();
   if (grid > n_chunks) grid = n_chunks;
+#ifdef X32_PHASE_PROFILE
+  if (MODE == 0) {   // development only: synchronous, prints to stderr
+    static float* dbg = nullptr;
+    if (!dbg) NFOPP_HIP(hipMalloc(&dbg, 64));
+    NFOPP_HIP(hipMemsetAsync(dbg, 0, 64, stream));
+    OnfKernelArgs b = a;
+    b.ws_u = dbg;   // unused by this mode: carries the tick buffer
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), IMG_BYTES, stream, b, (const u32x4*)img, (const u32x4*)blob);
+    float h[16];
+    NFOPP_HIP(hipMemcpyAsync(h, dbg, 64, hipMemcpyDeviceToHost, stream));
+    NFOPP_HIP(hipStreamSynchronize(stream));
+    static int calls = 0;
+    if (++calls % 10 == 0) {
+      const char* names[7] = {"sampling", "L1", "L2", "L2T+logit", "dh1", "L1T", "tail+out"};
+      for (int w = 0; w < 2; ++w) {
+        float tot = 0;
+        for (int k = 0; k < 7; ++k) tot += h[8 * w + k];
+        fprintf(stderr, "[x32 phase profile] wave %d of %lld workgroups: %.0f ticks per workgroup\n", 4 * w, grid, tot / grid);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, "   %-10s %5.1f %%\n", names[k], 100.0f * h[8 * w + k] / tot);
+      }
+    }
+    return NFOPP_OK;
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), IMG_BYTES, stream, a, (const u32x4*)img, (const u32x4*)blob);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;

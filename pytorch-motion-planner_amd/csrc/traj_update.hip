@@ -13,6 +13,10 @@
 namespace nfopp {
 
 constexpr int TU_THREADS = 256;
+// LDS budget for the band columns of the boundary waypoints.  Their number and the band width both grow with the
+// velocity-Hessian weight (a user hyper-parameter the reference accepts at any value: w = 10, N = 512 needs 205 KB);
+// beyond the budget those waypoints read their coefficients from global memory tap by tap.
+constexpr size_t K2_BND_BUDGET = 32 * 1024;
 #ifndef NFOPP_K2_WAVES
 #define NFOPP_K2_WAVES 1   /* minimum waves per SIMD the register allocation aims at (A/B: 6 and 8 below) */
 #endif
@@ -33,6 +37,7 @@ struct TrajUpdateArgs {
   const float* hinv_band;
   int half_width;
   int interior_lo, interior_hi;  // waypoints whose band column equals column interior_lo bit for bit (Toeplitz interior)
+  int bnd_in_lds;                // the boundary waypoints' band columns are staged in LDS (they fit K2_BND_BUDGET)
   float* terms;
   const unsigned char* active;
 };
@@ -120,7 +125,8 @@ template <int D>
 __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel(const TrajUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = a.n;
-  const int W = a.half_width, NB_LO = a.interior_lo, NB = a.interior_lo + (N - a.interior_hi);  // boundary columns
+  const int W = a.half_width, NB_LO = a.interior_lo;
+  const int NB = a.bnd_in_lds ? a.interior_lo + (N - a.interior_hi) : 0;  // boundary columns staged in LDS
   float* Q = sm;                    // (N+2) * D full trajectory
   float* GP = Q + (N + 2) * D;      // (N + 2W) * D gradient, W zero rows on either side: every tap of every waypoint is
   float* G = GP + W * D;            //   in range, so the band loop is uniform over the workgroup
@@ -270,13 +276,23 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
 #pragma unroll
     for (int d = 0; d < D; ++d) { m_in[d] = am[w * D + d]; v_in[d] = av[w * D + d]; }
     const bool interior = w >= a.interior_lo && w < a.interior_hi;
-    const float* cf = interior ? COEF : BND + (w < a.interior_lo ? w : NB_LO + (w - a.interior_hi)) * (2 * W + 1);
     const float* gj = GP + w * D;   // row w - W of the unpadded gradient
+    if (interior || a.bnd_in_lds) {
+      const float* cf = interior ? COEF : BND + (w < a.interior_lo ? w : NB_LO + (w - a.interior_hi)) * (2 * W + 1);
 #pragma unroll 4
-    for (int k = 0; k <= 2 * W; ++k) {
-      const float hv = cf[k];
+      for (int k = 0; k <= 2 * W; ++k) {
+        const float hv = cf[k];
 #pragma unroll
-      for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
+      }
+    } else {   // boundary waypoint, columns not staged: the same taps in the same order, coefficients from global memory
+      const float* cf = a.hinv_band + w;
+#pragma unroll 4
+      for (int k = 0; k <= 2 * W; ++k) {
+        const float hv = cf[(long long)k * N];
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(hv, gj[k * D + d], acc[d]);
+      }
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -333,7 +349,9 @@ extern "C" int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int3
   a.adam_m = adam_m_dev; a.adam_v = adam_v_dev; a.t = t_dev; a.onf = onf_out4_dev;
   a.hinv_band = hinv_band_dev; a.half_width = half_width; a.terms = terms_dev; a.active = active_dev;
   a.interior_lo = interior_lo; a.interior_hi = interior_hi > interior_lo ? interior_hi : interior_lo;
-  const int n_boundary = a.interior_lo + (n_waypoints - a.interior_hi);
+  int n_boundary = a.interior_lo + (n_waypoints - a.interior_hi);
+  a.bnd_in_lds = (size_t)n_boundary * (2 * half_width + 1) * 4 <= K2_BND_BUDGET;
+  if (!a.bnd_in_lds) n_boundary = 0;
   const size_t lds = (size_t)((n_waypoints + 2) * dim + (n_waypoints + 2 * half_width) * dim + 2 * n_waypoints + 1 +
                               (n_boundary + 1) * (2 * half_width + 1) + NFOPP_NUM_TERMS * (TU_THREADS / 64)) * 4;
   NFOPP_REQUIRE(lds <= 160 * 1024, "trajectory too long for one workgroup's LDS (%zu bytes)", lds);

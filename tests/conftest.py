@@ -33,30 +33,35 @@ def max_abs(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
 
 
-# Gates for the fixtures made with the benchmarked settings (tests/golden/traj_benchmr_*.npz: scripts/run_bench_mr.py
+# Gates for the fixtures made with the benchmarked settings (tests/golden/traj_benchmr_*.npz, g14: scripts/run_bench_mr.py
 # hyper block -- w_col 100, beta 10, w_dir 100, lr 5e-2 -- on the 100 m random-disc map).  That configuration is far
-# stiffer than scripts/benchmark.py's: the reference itself, restarted from the fixture's state with every coordinate
-# moved by ONE fp32 ulp, ends (xy, theta, lambda, cm) = (1.5e-5, 3e-6, 2e-6, 1e-8) away after 1 step at N=256
-# [(3.8e-5, 1.0e-4, 2.7e-5, 7e-7) at N=512], (1.5e-3, 5e-5, 5e-5, 9e-7) after 10 and (8.4e-3, 6.7e-3, 2.7e-3, 6e-5)
-# after 50 steps (measured in the build container, torch 2.10 CPU).  Gates = about 4x that conditioning; cm after 50
-# steps 10x (one perturbed ulp is the FLOOR of what a different summation order does in every step: the fp32 matrix path
-# measured 3.5e-4 there, the split path 2.9e-5, both with collision samples that are the reference's bit for bit;
-# tools/gpu_benchmr_margins.py prints all of these).
-BENCHMR_ROLLOUT_TOL = {1: dict(xy=1.5e-4, th=4e-4, lam=1e-4, cm=3e-6),
-                       10: dict(xy=6e-3, th=2e-3, lam=1e-3, cm=1e-5),
-                       50: dict(xy=3e-2, th=3e-2, lam=1e-2, cm=6e-4)}
+# stiffer than scripts/benchmark.py's, so the gates are DERIVED from the reference's own conditioning, measured by
+# tools/ref_conditioning.py (build container: the reference restarted from the fixture state with every trajectory
+# coordinate moved by ONE fp32 ulp, 6 random sign patterns, distance to the unperturbed run) and stored in
+# tests/golden/g17_conditioning.npz:
+#   rollouts  gate = 4 x that spread per quantity (xy, theta, lambda, cm) up to 10 steps, 8 x after 50 (a different
+#             summation order perturbs every step by an ulp, not only the start)
+#   g14       (B = 4 from the straight-line start: zero-up-to-rounding gradient entries become +-lr Adam moves, so single
+#             entries flip in the reference itself -- 2 lr = 0.1 after ONE step) maximum gate = 1.5 x the spread's
+#             maximum; the bulk (99th / 90th percentile) is a regression gate at about 5 x what tools/gpu_benchmr_margins.py
+#             measures on MI355X (its output: profiles/r03_benchmr_margins.txt) -- far below the reference's own bulk spread
+CONDITIONING = load_golden("g17_conditioning.npz")
 BENCHMR_FIXTURES = [("traj_benchmr_n256.npz", (1, 10, 50)), ("traj_benchmr_n512.npz", (1, 10))]
-# g14 (B = 4, 12 steps FROM the straight-line initialisation, snapshots after steps 1 / 3 / 12).  On a straight line many
-# gradient entries are zero up to rounding and Adam's first steps turn each into a full +-lr move, so single entries are
-# ill-conditioned in the reference itself: restarted 1 ulp away it ends max (xy, theta, lambda, cm) = (0.10, 0.10, 2e-6,
-# 2e-8) away after ONE step (= 2 lr: a sign flip), (0.09, 0.14, 0.026, 4e-8) after 3 and (0.14, 0.23, 0.035, 8.6e-4)
-# after 12.  Gates: the bulk of the entries (99th / 90th percentile of |difference|) tightly, the maximum at that
-# conditioning.  Measured on MI355X (tools/gpu_benchmr_margins.py): p99 0 / 9e-4 (xy, steps 1 / 3), p90 4e-4 (step 12).
-BENCHMR_BATCH_TOL = {
-    1: dict(q=99, xy=(1e-5, 0.11), th=(2e-5, 0.11), lam=(1e-7, 1e-5), cm=(1e-7, 1e-6)),
-    3: dict(q=99, xy=(5e-3, 0.15), th=(5e-3, 0.2), lam=(2e-4, 0.05), cm=(1e-7, 1e-6)),
-    12: dict(q=90, xy=(2e-3, 0.15), th=(1e-3, 0.25), lam=(4e-4, 0.05), cm=(1e-5, 1e-3)),
-}
+
+
+def benchmr_rollout_tol(name, K):
+    tag = name.replace("traj_benchmr_", "").replace(".npz", "")
+    s = CONDITIONING["rollout_%s_k%d" % (tag, K)] * (4.0 if K <= 10 else 8.0)
+    return dict(xy=float(s[0]), th=float(s[1]), lam=float(s[2]), cm=float(s[3]))
+
+
+_BATCH_BULK = {1: dict(q=99, xy=1e-5, th=2e-5, lam=1e-7, cm=1e-7), 3: dict(q=99, xy=5e-3, th=5e-3, lam=2e-4, cm=1e-7),
+               12: dict(q=90, xy=2e-3, th=1e-3, lam=4e-4, cm=1e-5)}
+BENCHMR_BATCH_TOL = {}
+for _k, _bulk in _BATCH_BULK.items():
+    _mx = CONDITIONING["batch_k%d_max" % _k] * 1.5
+    assert int(CONDITIONING["batch_k%d_q" % _k]) == _bulk["q"]
+    BENCHMR_BATCH_TOL[_k] = dict(q=_bulk["q"], **{name: (_bulk[name], float(_mx[i])) for i, name in enumerate(("xy", "th", "lam", "cm"))})
 
 
 def abs_percentile(a, b, q):

@@ -709,6 +709,35 @@ def g15_full_steps_n256():
     np.savez_compressed(os.path.join(HERE, "g15_full_steps_n256.npz"), **out)
 
 
+def g18_run_planner_script():
+    """BASELINE configs[0] as scripts/run_planner.py:10-66 runs it: make_car_environment(), the off-centre
+    RectangleCollisionChecker((-0.3, 0.2, -0.3, 0.2), (0, 3, 0, 3)) with only update_obstacle_points called on it, seeds
+    torch 100 / numpy 400, the script's parameter block (= params(100)), six full `.step()`s with ONF learning."""
+    torch.random.manual_seed(100)
+    np.random.seed(400)
+    env = TestEnvironmentBuilder().make_car_environment()
+    cc = RectangleCollisionChecker((-0.3, 0.2, -0.3, 0.2), (0, 3, 0, 3))
+    cc.update_obstacle_points(env.obstacle_points)
+    planner = PlannerFactory.make_constrained_onf_planner(cc, params(100))
+    planner.init(env.start_point, env.goal_point, env.bounds)
+    out = {"obstacles": env.obstacle_points.astype(np.float64), "bounds": np.asarray(env.bounds, np.float64),
+           "start": env.start_point, "goal": env.goal_point, "box": np.asarray((-0.3, 0.2, -0.3, 0.2), np.float64),
+           "checker_bounds": np.asarray((0, 3, 0, 3), np.float64),
+           "params0": flat_params(planner._collision_model), "traj0": planner._trajectory.detach().numpy().copy()}
+    K = 6
+    for k in range(K):
+        planner.step()
+        out["k%d_traj" % k] = planner._trajectory.detach().numpy().copy()
+        out["k%d_checked" % k] = planner.checked_positions.as_vec().astype(np.float64)
+        out["k%d_truth" % k] = np.asarray(planner.truth_collision).astype(np.uint8)
+        if k in (0, K - 1):
+            out["k%d_params" % k] = flat_params(planner._collision_model)
+        out["k%d_lam" % k] = planner._constraint_multipliers.detach().numpy().copy()
+        out["k%d_cm" % k] = planner._collision_multipliers.detach().numpy().copy()
+    out["steps"] = np.asarray(K)
+    np.savez_compressed(os.path.join(HERE, "g18_run_planner_script.npz"), **out)
+
+
 def corridor_grid(rows=100, cols=100, radius=3, seed=3, walkers=5, steps=150):
     """Stand-in for bench-mr's corridor grid generator (absent): random-walk corridors of the given radius carved out
     of a fully occupied 100 x 100 grid.  Our own generator -- the GRID is the committed fixture."""
@@ -779,7 +808,7 @@ def _register():
         g11=g11_init_and_checkers, g12=g12_init_direction_and_postprocess,
         benchmr=lambda: g14_benchmr_batch(g13_benchmr("n256", 256, 60, [8, 12, 0.3], [90, 86, -2.5], (1, 10, 50), 4096, False)),
         benchmr_n512=lambda: g13_benchmr("n512", 512, 40, [92, 9, 2.4], [10, 90, 0.7], (1, 10), 2000, True),
-        g15=g15_full_steps_n256, g16=g16_grid_checker)
+        g15=g15_full_steps_n256, g16=g16_grid_checker, g18=g18_run_planner_script)
 
 
 if __name__ == "__main__":

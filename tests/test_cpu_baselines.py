@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import BENCHMR_ROLLOUT_TOL, load_golden, max_abs, max_rel
+from conftest import benchmr_rollout_tol, load_golden, max_abs, max_rel
 from oracle import cpu_baselines as cb
 from oracle import nfopp_oracle as orc
 
@@ -33,7 +33,7 @@ def _scaled(a, b):
 
 def _rollout_tol(name, K):
     if "benchmr" in name:
-        return BENCHMR_ROLLOUT_TOL[K]
+        return benchmr_rollout_tol(name, K)
     return dict(xy=2e-5, th=4e-5, lam=6e-4, cm=2e-5)     # the K = 10 gates of tests/test_oracle_golden.py::test_g6_rollouts
 
 

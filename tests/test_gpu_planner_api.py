@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, max_abs
+from conftest import abs_percentile, load_golden, max_abs
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,39 @@ def test_full_steps_with_onf_learning_follow_the_reference():
     assert np.array_equal(path[0], z["start"]) and np.array_equal(path[-1], z["goal"])
     assert planner._step_count == int(z["steps"])
     assert float(planner.last_onf_loss) > 0
+
+
+def test_run_planner_script_configuration_follows_the_reference():
+    """BASELINE configs[0] as scripts/run_planner.py:10-66 runs it: car environment, the off-centre rectangle robot
+    (-0.3, 0.2, -0.3, 0.2) with checker bounds (0, 3, 0, 3) and ONLY update_obstacle_points called on the checker,
+    seeds 100 / 400, six full `.step()`s with ONF learning (fixture g18, made by running the reference)."""
+    z = load_golden("g18_run_planner_script.npz")
+    torch.random.manual_seed(100)
+    np.random.seed(400)
+    cc = nfopp.RectangleCollisionChecker(tuple(z["box"]), tuple(z["checker_bounds"]))
+    cc.update_obstacle_points(z["obstacles"])
+    planner = nfopp.PlannerFactory.make_constrained_onf_planner(cc, _params(100))
+    planner.init(z["start"], z["goal"], tuple(z["bounds"]))
+    assert np.array_equal(planner._collision_model.flat_parameters.cpu().numpy(), z["params0"])
+    assert max_abs(planner._trajectory.detach().cpu().numpy(), z["traj0"]) < 1e-6
+    for k in range(int(z["steps"])):
+        planner.step()
+        checked = planner.checked_positions.as_vec()
+        assert checked.shape == z["k%d_checked" % k].shape
+        tol = 2e-6 * 4 ** k
+        assert max_abs(checked[:99], z["k%d_checked" % k][:99]) < max(tol, 1e-5)
+        assert max_abs(checked[-10:], z["k%d_checked" % k][-10:]) < 1e-12
+        if max_abs(checked, z["k%d_checked" % k]) < 1e-4:   # same retained pool (see the g9 test): identical labels
+            assert np.array_equal(np.asarray(planner.truth_collision).astype(np.uint8), z["k%d_truth" % k])
+        assert max_abs(planner._trajectory.detach().cpu().numpy(), z["k%d_traj" % k]) < 5e-6 * 4 ** k
+        if ("k%d_params" % k) in z.files:
+            # Adam's first steps: an entry whose gradient is ~eps moves by lr * g / (|g| + eps) (lr 5e-2), so a rounding-level
+            # change of g shows in single entries (the g15 test has the account): the bulk tightly, the maximum loosely
+            got = planner._collision_model.flat_parameters.cpu().numpy()
+            assert abs_percentile(got, z["k%d_params" % k], 99) < 2e-7 * 4 ** k
+            assert max_abs(got, z["k%d_params" % k]) < 2e-3
+        assert max_abs(planner._constraint_multipliers.cpu().numpy(), z["k%d_lam" % k]) < 2e-5 * 4 ** k
+        assert max_abs(planner._collision_multipliers.cpu().numpy(), z["k%d_cm" % k]) < 2e-5 * 4 ** k
 
 
 def test_update_goal_and_start_point_vs_golden():

@@ -50,9 +50,10 @@ def test_param_count_and_argument_errors_without_gpu():
     assert lib.nfopp_path_postprocess(None, 0, 10, 0.001, 0.05, 0, None, None, None) == 0     # empty batch: no-op
     assert lib.nfopp_init_trajectories(None, None, 1, 10, 2, 1, None, None) == -1             # headings need dim 3
     assert lib.nfopp_init_trajectories(None, None, 0, 10, 3, 0, None, None) == 0
-    assert lib.nfopp_set_matrix_path(2) == -1 and b"matrix path" in lib.nfopp_last_error()
+    assert lib.nfopp_set_matrix_path(3) == -1 and b"matrix path" in lib.nfopp_last_error()
     before = lib.nfopp_get_matrix_path()
-    assert before in (0, 1)
+    assert before in (0, 1, 2)
+    assert lib.nfopp_set_matrix_path(2) == 0 and lib.nfopp_get_matrix_path() == 2     # split, 16x16x32 kernels only
     assert lib.nfopp_set_matrix_path(0) == 0 and lib.nfopp_get_matrix_path() == 0
     assert lib.nfopp_set_matrix_path(1) == 0 and lib.nfopp_get_matrix_path() == 1
     assert lib.nfopp_set_matrix_path(before) == 0
