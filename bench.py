@@ -241,7 +241,7 @@ def pmc_traffic(workload, batch, n):
     with tools/gpu_pmc_split.sh on the cfg3 workload in separate --pmc passes); None for other workloads."""
     if (workload, batch, n) != ("cfg3", B_PER_GPU, 256):
         return None, None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)["bytes_per_launch"]), "profiles/" + name
@@ -256,10 +256,12 @@ def roofline(matrix_path, achieved, k1_ms, samples, traffic, traffic_source):
     so the peak that bounds it is the dense bf16 peak / 6 (fp32-equivalent); the fp32-MFMA ratio is given beside it."""
     out = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_source,
            "kernel_ms": k1_ms, "algorithmic_flop_per_launch": samples * FLOP_PER_SAMPLE}
-    if matrix_path == "split":
+    if matrix_path in ("split", "split16"):
         peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
-        out.update({"peak": peak, "frac": achieved / peak, "kernel": "onf_split_kernel<14,2,0>",
-                    "pipe": "bf16 MFMA 16x16x32, %d partial products per fp32 multiply (exact 3-level operand split)" % SPLIT_PRODUCTS,
+        x32 = matrix_path == "split"
+        out.update({"peak": peak, "frac": achieved / peak, "kernel": "onf_x32_kernel<14,0>" if x32 else "onf_split_kernel<14,2,0>",
+                    "pipe": "bf16 MFMA %s, %d partial products per fp32 multiply (exact 3-level operand split)"
+                            % ("32x32x16" if x32 else "16x16x32", SPLIT_PRODUCTS),
                     "pipe_peak": PEAK_BF16_MFMA_TFLOPS, "executed_tflops": achieved * SPLIT_PRODUCTS,
                     "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS})
     else:
@@ -280,15 +282,16 @@ def main():
     ap.add_argument("--parity-steps", type=int, default=10)
     ap.add_argument("--workload", choices=("cfg3", "cfg4", "cfg5"), default="cfg3")
     ap.add_argument("--spin-up", type=int, default=300, help="throw-away steps during setup (clock ramp), state reset after")
-    ap.add_argument("--matrix-path", choices=("split", "fp32"), default=None,
-                    help="fused ONF kernel: bf16x3 split-precision MFMA (library default, fp32-faithful) or fp32 MFMA; "
-                         "not given = leave the library's choice (NFOPP_MATRIX_PATH) alone")
+    ap.add_argument("--matrix-path", choices=("split", "split16", "fp32"), default=None,
+                    help="fused ONF kernel: bf16x3 split-precision MFMA on 32x32x16 tiles (library default, fp32-faithful), the "
+                         "same arithmetic on round 2's 16x16x32 kernel, or fp32 MFMA; not given = leave the library's choice "
+                         "(NFOPP_MATRIX_PATH) alone")
     args = ap.parse_args()
     from nfopp import _lib
     lib = _lib.load()
     if args.matrix_path is not None:
-        _lib.check(lib.nfopp_set_matrix_path(1 if args.matrix_path == "split" else 0))
-    matrix_path = "split" if lib.nfopp_get_matrix_path() == 1 else "fp32"
+        _lib.check(lib.nfopp_set_matrix_path({"split": 1, "split16": 2, "fp32": 0}[args.matrix_path]))
+    matrix_path = {1: "split", 2: "split16", 0: "fp32"}[lib.nfopp_get_matrix_path()]
     N = 512 if args.workload == "cfg5" else 256
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

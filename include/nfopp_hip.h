@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NFOPP_ABI_VERSION 4
+#define NFOPP_ABI_VERSION 5
 #define NFOPP_HIDDEN 100 /* width of both hidden layers, nfop/onf_model.py:18-23 */
 
 typedef enum nfopp_status {
@@ -219,6 +219,14 @@ int nfopp_path_select_best(const float* labels_dev, const float* length_dev, con
  *   kernel in front of every evaluation on the caller's stream), at most 16 per device: a 17th stream reuses the least
  *   recently used slot after a device synchronisation. */
 int nfopp_set_matrix_path(int32_t path);
+/* Content version of an ONF parameter buffer on the current device (ABI 5).  The split matrix paths evaluate the field from
+ * a pre-split image of the weights that a small kernel rebuilds from params_dev in front of EVERY launch, because the
+ * library cannot see whether the caller changed the buffer.  A caller who knows can vouch for it: register a non-zero
+ * `version` that it changes whenever the buffer's contents change; while (buffer, version, configuration) stay the same,
+ * launches on a stream reuse that stream's image and skip the rebuild (a frozen field: one launch less per planner step).
+ * version = 0 withdraws the registration; nfopp_adam_step withdraws it for the buffer it updates.  Versions must be unique
+ * per content over the life of the process (a counter), not per buffer. */
+int nfopp_onf_params_version(const float* params_dev, uint64_t version);
 int nfopp_get_matrix_path(void);
 
 /* ---- the steps either side of the planner step ----------------------------------------

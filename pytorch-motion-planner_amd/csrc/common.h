@@ -34,6 +34,9 @@ int current_device();   // hipGetDevice, -1 on failure (error string set)
 // Raises the dynamic-LDS limit of `kernel` on the current device the first time it is launched there.
 // `flags` is the caller's static bool[MAX_DEVICES] for that kernel instantiation.
 int ensure_dynamic_lds(const void* kernel, size_t bytes, bool* flags);
+// Content version the caller registered for a parameter buffer on the current device (nfopp_onf_params_version), 0 = none.
+unsigned long long onf_params_version_of(const float* params_dev);
+void onf_params_invalidate(const float* params_dev);
 
 // ---- ONF parameter buffer geometry (state_dict order, include/nfopp_hip.h) --------------------------------------
 struct OnfGeom {

@@ -26,6 +26,7 @@
 // onf_split.hip.  Small launches (fewer samples than one 256-sample chunk per CU) also stay there: its 16-sample tiles
 // spread them over more CUs.
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <type_traits>
@@ -263,7 +264,11 @@ __device__ __forceinline__ void eval_item(EvalState& s, const f32x4& tw, float u
   if constexpr (U == 7) s.v = __builtin_amdgcn_sinf(s.v);
 }
 
-constexpr int CH = 8 * 32;   // samples per workgroup pass: 8 waves x one 32-sample tile
+#ifndef X32_THREADS
+#define X32_THREADS 512   /* development A/B: 256 = one wave per SIMD (512 registers a wave) */
+#endif
+constexpr int XT = X32_THREADS;
+constexpr int CH = (XT / 64) * 32;   // samples per workgroup pass: 8 waves x one 32-sample tile
 
 // Development build (make EXTRA=-DX32_PHASE_PROFILE): waves 0 and 4 of every workgroup accumulate clock ticks per phase of the
 // chunk loop; launch_t prints the shares every tenth launch of the mode-0 kernel (synchronous, stderr).
@@ -279,26 +284,26 @@ constexpr int CH = 8 * 32;   // samples per workgroup pass: 8 waves x one 32-sam
 #endif
 
 template <int NKB, int MODE>
-__global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, const u32x4* __restrict__ img,
+__global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelArgs a, const u32x4* __restrict__ img,
                                                          const u32x4* __restrict__ blob) {
   using C = Cfg<NKB>;
   constexpr bool FWD_ONLY = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   {   // image -> LDS, four 16-byte pieces per thread in flight
     constexpr int N16 = IMG_BYTES / 16;
-    for (int k0 = threadIdx.x; k0 < N16; k0 += 4 * 512) {
+    for (int k0 = threadIdx.x; k0 < N16; k0 += 4 * XT) {
       u32x4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (k0 + 512 * q < N16) v[q] = img[k0 + 512 * q];
+      for (int q = 0; q < 4; ++q) if (k0 + XT * q < N16) v[q] = img[k0 + XT * q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (k0 + 512 * q < N16) reinterpret_cast<u32x4*>(lds)[k0 + 512 * q] = v[q];
+      for (int q = 0; q < 4; ++q) if (k0 + XT * q < N16) reinterpret_cast<u32x4*>(lds)[k0 + XT * q] = v[q];
     }
   }
   __syncthreads();
   // static priority for the younger half (MI355X_MICROARCH.md); the condition must be provably wave-uniform, or hipcc
   // lowers it to an exec mask around an UNCONDITIONAL s_setprio
 #ifndef X32_NO_PRIO
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+  if (XT == 512 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
 
   const OnfGeom& geo = a.geom;
@@ -355,27 +360,39 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
   float phase_ticks[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   unsigned long long phase_t0 = __builtin_readcyclecounter();
 #endif
-  // The loads of a chunk's samples (and the first three third-level fragments) are issued during the PREVIOUS chunk's
-  // last GEMM, so that no chunk starts by waiting for global memory.
-  if (n_chunks <= (long long)blockIdx.x) return;   // (an empty live list: nothing to do, and no sample to prefetch)
-  RawPoint raw;
-  point_fetch(a, n_work, (long long)blockIdx.x * CH + wave * 32 + j, raw);
+  if (n_chunks <= (long long)blockIdx.x) return;   // (an empty live list: nothing to do)
   // third-level fragments: ring of 4, three steps ahead, running on across the GEMMs (blob steps are consecutive) and,
   // at the end of a chunk, on into the first steps of the next
   u32x4 fl[4];
   fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
+  // Samples.  Both lane halves of a wave need the wave's 32 poses, so forming them in all 64 lanes does every draw,
+  // interpolation and normalisation twice.  Instead every OTHER chunk the lower half forms this chunk's poses and the
+  // upper half the next chunk's, and the halves exchange them (5 cross-half moves): the sampling arithmetic runs once
+  // per pose.  (Each pose is still formed by exactly one lane, with the arithmetic of load_point: same bits.)
+  float nux = 0.f, nuy = 0.f, nth = 0.f;
+  long long npidx = 0;
+  bool have_next = false;
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     float ux, uy, th;
     long long pidx;
     // table bases: opaque per chunk, so that (base + small constant) stays an immediate offset of the LDS read instead
     // of one hoisted register per constant
     asm volatile("" : "+v"(ftl), "+v"(ftdl), "+v"(isl), "+v"(w3al), "+v"(w3ll), "+v"(fin_rel));
-    {
+    if (have_next) {
+      ux = nux; uy = nuy; th = nth; pidx = npidx;
+      have_next = false;
+    } else {
       float x, y, ang;
-      pidx = point_finish(a, raw, g, x, y, ang);
-      ux = (x - geo.mean) / geo.sigma;
-      uy = (y - geo.mean) / geo.sigma;
-      th = ang;
+      const long long mine = chunk + (g ? (long long)gridDim.x : 0);   // past the last chunk: padding lanes (nothing stored)
+      const long long row = load_point(a, n_work, mine * CH + wave * 32 + j, 0, x, y, ang);
+      const float sx = (x - geo.mean) / geo.sigma, sy = (y - geo.mean) / geo.sigma;
+      const int rlo = (int)row, rhi = (int)(row >> 32);
+      const float ox = __shfl_xor(sx, 32), oy = __shfl_xor(sy, 32), oa = __shfl_xor(ang, 32);
+      const int olo = __shfl_xor(rlo, 32), ohi = __shfl_xor(rhi, 32);
+      const long long orow = ((long long)ohi << 32) | (unsigned)olo;
+      ux = g ? ox : sx; uy = g ? oy : sy; th = g ? oa : ang; pidx = g ? orow : row;
+      nux = g ? sx : ox; nuy = g ? sy : oy; nth = g ? ang : oa; npidx = g ? row : orow;
+      have_next = true;
     }
     u32x4 fh[2], fm[2];   // hi / mid fragments: this step and the next
 
@@ -402,10 +419,6 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
     X32_TICK(0)   // sampling
     // ================================================================ L1: a1 = W1ext in
     f32x16 acc1[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
     {
       int w1f[2][2];
       bases_w1f(w1f);
@@ -443,8 +456,9 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
         }
       };
       // MFMA steps of block kb (fragments in bc), preparing block kb + 1 into bn when HOOK
-      auto l1_block = [&](auto hook_c, auto par_c, int kb, const u32x4 (&bc)[3], u32x4 (&bn)[3]) __attribute__((always_inline)) {
+      auto l1_block = [&](auto hook_c, auto par_c, int kb, const u32x4 (&bc)[3], u32x4 (&bn)[3], auto first_c) __attribute__((always_inline)) {
         constexpr bool HOOK = decltype(hook_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;   // block 0: the accumulators start here
         constexpr int PAR = decltype(par_c)::value;   // parity of kb
         const int kq = 64 * (kb >> 1);
         if constexpr (HOOK) { nxt_ft = ftl + 256 * (kb + 1); load_pair(0); }
@@ -462,25 +476,27 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
           }
           fl[(mt + 3) & 3] = lo_frag(C::S_L1 + 4 * kb + mt + 3);
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * mt>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[mt], bc, [&](auto slot) {
+          step6<6 * mt, FIRST>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[mt], bc, [&](auto slot) {
             if constexpr (HOOK) sfor<0, 5>([&](auto i) { l1_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}, bn); });
           });
         });
       };
       constexpr int FS = C::FS;
       fh[0] = lds128(lds, O_W1H + w1f[0][0]); fm[0] = lds128(lds, w1m[0][0]);
+      l1_block(std::true_type{}, ic<0>{}, 0, bA, bB, std::true_type{});
+      l1_block(std::true_type{}, ic<1>{}, 1, bB, bA, std::false_type{});
 #pragma unroll 1
-      for (int kp = 0; kp < FS / 2 - 1; ++kp) {
-        l1_block(std::true_type{}, ic<0>{}, 2 * kp, bA, bB);
-        l1_block(std::true_type{}, ic<1>{}, 2 * kp + 1, bB, bA);
+      for (int kp = 1; kp < FS / 2 - 1; ++kp) {
+        l1_block(std::true_type{}, ic<0>{}, 2 * kp, bA, bB, std::false_type{});
+        l1_block(std::true_type{}, ic<1>{}, 2 * kp + 1, bB, bA, std::false_type{});
       }
-      l1_block(std::true_type{}, ic<0>{}, FS - 2, bA, bB);
-      l1_block(std::false_type{}, ic<1>{}, FS - 1, bB, bA);
+      l1_block(std::true_type{}, ic<0>{}, FS - 2, bA, bB, std::false_type{});
+      l1_block(std::false_type{}, ic<1>{}, FS - 1, bB, bA, std::false_type{});
       // blocks with angle / ones / pad features: evaluated up front
       sfor<FS, NKB>([&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
         features_upfront(std::true_type{}, kb, bA);
-        l1_block(std::false_type{}, ic<(kb & 1)>{}, kb, bA, bB);
+        l1_block(std::false_type{}, ic<(kb & 1)>{}, kb, bA, bB, std::false_type{});
       });
     }
     X32_TICK(1)   // L1
@@ -546,7 +562,6 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
       float lg = lgs[0] + lgs[1] + (g == 1 ? skipv : 0.0f);
       lg += __shfl_xor(lg, 32);
       if (g == 0 && pidx < a.n_points) *reinterpret_cast<f32x4*>(a.out4 + pidx * 4) = f32x4{lg, 0.f, 0.f, 0.f};
-      point_fetch(a, n_work, (chunk + gridDim.x) * CH + wave * 32 + j, raw);
       fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
       continue;
     }
@@ -710,8 +725,6 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
         fhn = lds_tr(lds, O_W1H + t1[0][0], O_W1H + t1[1][0]);
         fmn = lds_tr(lds, t1m[0][0], t1m[1][0]);
       }
-      point_fetch(a, n_work, (chunk + gridDim.x) * CH + wave * 32 + j, raw);   // next chunk's samples (finished at its start)
-      __builtin_amdgcn_sched_barrier(0);
       l1t_tile(std::false_type{}, 0, accp);
 #pragma unroll 1
       for (int mt = 1; mt < C::NMT; ++mt) {
@@ -738,12 +751,16 @@ __global__ __launch_bounds__(512, 2) void onf_x32_kernel(const OnfKernelArgs a, 
 // Image + blob per (device, stream): the prep kernel rewrites them on the launch stream in front of every launch (the
 // parameters may have changed), so launches of one stream are ordered by the stream itself.
 constexpr int MAX_SLOTS = 16;
-struct Slot { hipStream_t stream; void* ptr; size_t bytes; bool used; unsigned long long stamp; };
+struct Slot {
+  hipStream_t stream; void* ptr; size_t bytes; bool used; unsigned long long stamp;
+  // what the image in `ptr` was built from: parameter buffer, its registered content version (0 = unknown), geometry
+  const float* params; unsigned long long version; OnfGeom geom; int nkb;
+};
 static Slot g_slots[MAX_DEVICES][MAX_SLOTS] = {};
 static unsigned long long g_stamp = 0;
 static std::mutex g_mutex;
 
-static int buffers_for_stream(size_t bytes, hipStream_t stream, void** out) {
+static int buffers_for_stream(size_t bytes, hipStream_t stream, void** out, Slot** slot_out) {
   const int dev = current_device();
   if (dev < 0) return NFOPP_ERR_HIP;
   std::lock_guard<std::mutex> lock(g_mutex);
@@ -759,15 +776,17 @@ static int buffers_for_stream(size_t bytes, hipStream_t stream, void** out) {
       if (g_slots[dev][k].stamp < slot->stamp) slot = &g_slots[dev][k];
     NFOPP_HIP(hipDeviceSynchronize());
   }
+  if (slot->stream != stream) slot->version = 0;   // another stream's image: never trusted
   slot->stream = stream;
   slot->stamp = ++g_stamp;
   if (slot->bytes < bytes) {
     if (slot->ptr) NFOPP_HIP(hipFree(slot->ptr));
-    slot->ptr = nullptr; slot->bytes = 0;
+    slot->ptr = nullptr; slot->bytes = 0; slot->version = 0;
     NFOPP_HIP(hipMalloc(&slot->ptr, bytes));
     slot->bytes = bytes;
   }
   *out = slot->ptr;
+  *slot_out = slot;
   return NFOPP_OK;
 }
 
@@ -779,13 +798,24 @@ static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
   int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), IMG_BYTES, attr_set);
   if (rc != NFOPP_OK) return rc;
   void* buf = nullptr;
-  rc = buffers_for_stream(IMG_BYTES + C::BLOB_BYTES, stream, &buf);
+  Slot* slot = nullptr;
+  rc = buffers_for_stream(IMG_BYTES + C::BLOB_BYTES, stream, &buf, &slot);
   if (rc != NFOPP_OK) return rc;
   u32x4* img = reinterpret_cast<u32x4*>(buf);
   u32x4* blob = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(buf) + IMG_BYTES);
-  constexpr int N_PIECES = IMG_BYTES / 16 + (C::STEPS + 4) * 64;
-  hipLaunchKernelGGL(x32_prep_kernel<NKB>, dim3((N_PIECES + 255) / 256), dim3(256), 0, stream, a.geom, a.params, img, blob);
-  NFOPP_HIP(hipGetLastError());
+  // The image is a function of the parameter values.  It is rebuilt in front of every launch unless the caller vouches
+  // for the buffer's content with a version (nfopp_onf_params_version) and this stream's image was built from that very
+  // (buffer, version, geometry): a frozen field then costs no prep launch.
+  const unsigned long long ver = onf_params_version_of(a.params);
+  const bool fresh = ver != 0 && slot->version == ver && slot->params == a.params && slot->nkb == NKB &&
+                     memcmp(&slot->geom, &a.geom, sizeof(OnfGeom)) == 0;
+  if (!fresh) {
+    constexpr int N_PIECES = IMG_BYTES / 16 + (C::STEPS + 4) * 64;
+    hipLaunchKernelGGL(x32_prep_kernel<NKB>, dim3((N_PIECES + 255) / 256), dim3(256), 0, stream, a.geom, a.params, img, blob);
+    NFOPP_HIP(hipGetLastError());
+    std::lock_guard<std::mutex> lock(g_mutex);
+    slot->params = a.params; slot->version = ver; slot->geom = a.geom; slot->nkb = NKB;
+  }
   const long long n_chunks = (a.n_points + CH - 1) / CH;
   long long grid = query_cus();
   if (grid > n_chunks) grid = n_chunks;
@@ -796,7 +826,7 @@ static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
     NFOPP_HIP(hipMemsetAsync(dbg, 0, 64, stream));
     OnfKernelArgs b = a;
     b.ws_u = dbg;   // unused by this mode: carries the tick buffer
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), IMG_BYTES, stream, b, (const u32x4*)img, (const u32x4*)blob);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(XT), IMG_BYTES, stream, b, (const u32x4*)img, (const u32x4*)blob);
     float h[16];
     NFOPP_HIP(hipMemcpyAsync(h, dbg, 64, hipMemcpyDeviceToHost, stream));
     NFOPP_HIP(hipStreamSynchronize(stream));
@@ -813,7 +843,7 @@ static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
     return NFOPP_OK;
   }
 #endif
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), IMG_BYTES, stream, a, (const u32x4*)img, (const u32x4*)blob);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(XT), IMG_BYTES, stream, a, (const u32x4*)img, (const u32x4*)blob);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;
 }

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnfopp_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_TERMS = 8
 TERM_NAMES = ("total", "distance", "softplus_sum", "lambda_dot_c", "c_squared", "boundary", "cm_tanh", "direction")
 
@@ -55,6 +55,7 @@ _SIGNATURES = {
                                               _P, _P, _P, _P, _P]),
     "nfopp_set_matrix_path": (ctypes.c_int, [ctypes.c_int32]),
     "nfopp_get_matrix_path": (ctypes.c_int, []),
+    "nfopp_onf_params_version": (ctypes.c_int, [_P, ctypes.c_uint64]),
     "nfopp_init_trajectories": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                _P, _P]),
     "nfopp_path_postprocess": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,

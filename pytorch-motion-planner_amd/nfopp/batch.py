@@ -85,6 +85,7 @@ class OnfFitter(object):
         _lib.check(_lib.load().nfopp_adam_step(_lib.ptr(self.onf.flat_parameters), _lib.ptr(self.grad), _lib.ptr(self.m),
                                                _lib.ptr(self.v), self.onf.n_params, b2, 1 - b1, 1 - b2, self.eps,
                                                step_size, bc2_sqrt, _lib.stream_ptr()))
+        self.onf.mark_modified()   # a raw-pointer write: torch's version counter does not see it
 
     def _in_group(self):
         return self.distributed and torch.distributed.is_available() and torch.distributed.is_initialized()

@@ -6,6 +6,7 @@ same constructor arguments, same `state_dict()` keys and shapes, same initialisa
 in `state_dict()` order -- the buffer the HIP kernels read directly (include/nfopp_hip.h, nfopp_onf_config).
 `forward` evaluates the field with the fused HIP kernel; there is no PyTorch arithmetic on this path.
 """
+import itertools
 import math
 
 import torch
@@ -14,6 +15,7 @@ from torch import nn
 from . import _lib
 
 HIDDEN = 100
+_CONTENT_VERSIONS = itertools.count(1)   # process-wide: a version names ONE content of ONE buffer, never reused
 
 
 class _Leaf(nn.Module):
@@ -59,7 +61,9 @@ class ONF(nn.Module):
 
     # ---- flat buffer <-> named views ----------------------------------------------------------------------------
     def _bind(self, flat):
+        self._withdraw_version()
         object.__setattr__(self, "_flat", flat.contiguous())
+        object.__setattr__(self, "_vouched", None)   # (data_ptr, torch version counter) the library holds a version for
         views, o = {}, 0
         for name, shape in self._layout:
             n = 1
@@ -105,7 +109,41 @@ class ONF(nn.Module):
         return self._flat.numel()
 
     def config_c(self):
+        """Configuration block of the C ABI.  Every launch that reads the parameters fetches it first, so this is also where
+        the buffer's content version is (re-)registered with the library (nfopp_onf_params_version): while the flat buffer
+        has not been written -- torch's version counter, which every in-place op on the buffer or on a parameter view
+        bumps, plus `mark_modified()` for writes torch cannot see -- the split kernels reuse their pre-split weight image
+        instead of rebuilding it in front of every launch."""
+        self._vouch()
         return _lib.OnfConfigC(self._mean, self._sigma, int(self._use_cos), int(self._bias), self._angle_dim)
+
+    def _vouch(self):
+        f = self._flat
+        if not f.is_cuda:
+            return
+        key = (f.data_ptr(), f._version)
+        if self._vouched != key:
+            lib = _lib.load()
+            with torch.cuda.device(f.device):
+                _lib.check(lib.nfopp_onf_params_version(f.data_ptr(), next(_CONTENT_VERSIONS)))
+            object.__setattr__(self, "_vouched", key)
+
+    def mark_modified(self):
+        """Call after writing the parameters in a way torch's version counter does not see (a raw-pointer kernel such as
+        nfopp_adam_step, or `.data` writes): the next launch re-registers a new content version."""
+        object.__setattr__(self, "_vouched", None)
+
+    def _withdraw_version(self):
+        f = getattr(self, "_flat", None)
+        if f is not None and f.is_cuda and getattr(self, "_vouched", None) is not None:
+            try:
+                with torch.cuda.device(f.device):
+                    _lib.load().nfopp_onf_params_version(f.data_ptr(), 0)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self._withdraw_version()
 
     # ---- evaluation (HIP only) ------------------------------------------------------------------------------------
     def _eval(self, x, with_grad):

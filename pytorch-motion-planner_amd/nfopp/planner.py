@@ -170,6 +170,7 @@ class NERFOptPlanner(ContinuousPlanner):
         _lib.check(lib.nfopp_adam_step(_lib.ptr(model.flat_parameters), _lib.ptr(self._onf_grad), _lib.ptr(self._onf_m),
                                        _lib.ptr(self._onf_v), model.n_params, b2, 1 - b1, 1 - b2, eps, lr / bc1,
                                        bc2 ** 0.5, _lib.stream_ptr()))
+        model.mark_modified()   # a raw-pointer write: torch's version counter does not see it
         self.last_onf_loss = self._onf_grad[model.n_params]
 
     def _calculate_truth_collision(self, positions):

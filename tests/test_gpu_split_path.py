@@ -123,3 +123,33 @@ def test_split_collision_eval_and_rollout(name, split_path):
         res.append(e.traj.cpu().numpy())
     _lib.check(split_path.nfopp_set_matrix_path(1))
     assert np.max(np.abs(res[0] - res[1])) < 2e-5
+
+
+def test_cached_weight_image_follows_the_parameters():
+    """ABI 5: while the ONF's flat buffer is unchanged (torch's version counter + mark_modified) launches reuse the stream's
+    pre-split weight image; any in-place write -- through the flat buffer, through a parameter view, or a raw-pointer
+    Adam step -- must show up in the very next evaluation."""
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z["a_cfg"], z["a_params"])
+    x = torch.tensor(z["a_x"], device="cuda")
+    lib = _lib.load()
+    base = onf.forward_with_grad(x).clone()
+    assert torch.equal(onf.forward_with_grad(x), base)              # cached image: same bits as a rebuilt one
+    _lib.check(lib.nfopp_onf_params_version(onf.flat_parameters.data_ptr(), 0))
+    onf.mark_modified()
+    assert torch.equal(onf.forward_with_grad(x), base)
+    with torch.no_grad():
+        getattr(onf.mlp, "0").weight.mul_(1.5)                                   # a parameter VIEW, in place
+    moved = onf.forward_with_grad(x).clone()
+    assert not torch.equal(moved, base)
+    with torch.no_grad():
+        onf.flat_parameters.copy_(torch.tensor(z["a_params"], device="cuda"))
+    assert torch.equal(onf.forward_with_grad(x), base)
+    # raw-pointer update by the library itself: the registration is withdrawn by nfopp_adam_step
+    g = torch.ones_like(onf.flat_parameters)
+    m, v = torch.zeros_like(g), torch.zeros_like(g)
+    _lib.check(lib.nfopp_adam_step(_lib.ptr(onf.flat_parameters), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), onf.n_params, 0.9, 0.1,
+                                   0.1, 1e-8, 0.05, 1.0, _lib.stream_ptr()))
+    after = onf.forward_with_grad(x)
+    torch.cuda.synchronize()
+    assert not torch.equal(after, base)

@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_header_symbol():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nfopp_abi_version() == 4
+    assert lib.nfopp_abi_version() == 5
     assert lib.nfopp_device_count() >= 0
 
 

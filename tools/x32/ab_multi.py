@@ -15,8 +15,9 @@ from nfopp import _lib
 def bind(path):
     lib = ctypes.CDLL(path)
     for name, (res, args) in _lib._SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = res, args
+        if hasattr(lib, name):                  # (a variant built before an ABI addition lacks the new symbols)
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
     return lib
 
 
@@ -35,9 +36,17 @@ out = {k: torch.zeros(B, N - 1, 4, device="cuda") for k in variants}
 cfg = onf.config_c()
 
 
+POINTS = os.environ.get("AB_MODE") == "points"      # explicit poses (nfopp_onf_eval_points) instead of trajectory sampling
+pts = traj[:, :-1].reshape(-1, 3).contiguous()
+
+
 def run(k):
     lib, mp = variants[k]
     lib.nfopp_set_matrix_path(mp)
+    if POINTS:
+        rc = lib.nfopp_onf_eval_points(cfg, _lib.ptr(onf.flat_parameters), _lib.ptr(pts), pts.shape[0], _lib.ptr(out[k]), _lib.stream_ptr())
+        assert rc == 0, lib.nfopp_last_error()
+        return
     rc = lib.nfopp_traj_collision_eval(cfg, _lib.ptr(onf.flat_parameters), _lib.ptr(traj), B, N, 3, _lib.ptr(t), 1, 7, 0, 0,
                                        _lib.ptr(out[k]), None, None, _lib.stream_ptr())
     assert rc == 0, lib.nfopp_last_error()
