@@ -8,8 +8,8 @@
 // `_optimize_trajectory` (nfop/nerf_opt_planner.py:143-155, nfop/constrained_nerf_opt_planner.py:63-130), the
 // reparametrisation (constrained:132-171, nerf:224-244) and one `_optimize_collision_model` step (nerf:76-91).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>    // PyTorch-ROCm names its HIP devices "cuda": these are the
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>       // guard / stream types that accept that device type
 #include <torch/library.h>
 
 #include "nfopp_hip.h"
@@ -44,7 +44,7 @@ void check_params(const Tensor& params, const nfopp_onf_config& c) {
   TORCH_CHECK(want > 0, "nfopp: bad ONF configuration");
   TORCH_CHECK(params.numel() == want, "nfopp: params has ", params.numel(), " elements, this ONF configuration has ", want);
 }
-void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream(); }
 
 // the 18 floats of nfopp_traj_hyper in declaration order
 nfopp_traj_hyper make_hyper(at::ArrayRef<double> h) {
@@ -65,7 +65,7 @@ Tensor onf_fwd_bwd_input(const Tensor& params, const Tensor& points, double mean
   same_device(params, points, "points");
   const int64_t dim = angle_dim > 0 ? 3 : 2;
   TORCH_CHECK(points.dim() == 2 && points.size(1) == dim, "nfopp: points must be [P, ", dim, "]");
-  c10::hip::HIPGuard guard(params.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
   Tensor out = at::empty({points.size(0), 4}, points.options());
   check_status(nfopp_onf_eval_points(&c, params.data_ptr<float>(), points.data_ptr<float>(), points.size(0),
                                      out.data_ptr<float>(), stream_of(params)));
@@ -81,7 +81,7 @@ Tensor onf_logits(const Tensor& params, const Tensor& points, double mean, doubl
   same_device(params, points, "points");
   const int64_t dim = angle_dim > 0 ? 3 : 2;
   TORCH_CHECK(points.dim() == 2 && points.size(1) == dim, "nfopp: points must be [P, ", dim, "]");
-  c10::hip::HIPGuard guard(params.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
   Tensor out = at::empty({points.size(0), 4}, points.options());
   check_status(nfopp_onf_eval_logits(&c, params.data_ptr<float>(), points.data_ptr<float>(), points.size(0),
                                      out.data_ptr<float>(), stream_of(params)));
@@ -128,7 +128,7 @@ void traj_step(const Tensor& params, double mean, double sigma, bool use_cos, bo
     TORCH_CHECK(live_ws->numel() >= B + 1, "nfopp: live_ws must hold B + 1 int32");
   }
   const nfopp_traj_hyper hp = make_hyper(hyper);
-  c10::hip::HIPGuard guard(traj.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(traj.device());
   void* st = stream_of(traj);
   check_status(nfopp_traj_collision_eval(&c, params.data_ptr<float>(), traj.data_ptr<float>(), B, (int32_t)N, (int32_t)D,
                                          t.data_ptr<float>(), (int32_t)t_mode, (uint64_t)seed, (uint64_t)rng_offset,
@@ -160,7 +160,7 @@ void reparametrize(Tensor traj, const Tensor& start, const Tensor& goal, const O
     check_tensor(*active, "active", at::kByte);
     TORCH_CHECK(active->numel() == B, "nfopp: active must be [B] uint8");
   }
-  c10::hip::HIPGuard guard(traj.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(traj.device());
   check_status(nfopp_reparametrize(B, (int32_t)N, (int32_t)D, traj.data_ptr<float>(), start.data_ptr<float>(),
                                    goal.data_ptr<float>(), opt_ptr<float>(lam), opt_ptr<float>(cm), u.data_ptr<float>(),
                                    opt_ptr<uint8_t>(active), stream_of(traj)));
@@ -176,7 +176,7 @@ Tensor onf_train_grad(const Tensor& params, const Tensor& samples, const Tensor&
   const int64_t dim = angle_dim > 0 ? 3 : 2;
   TORCH_CHECK(samples.dim() == 2 && samples.size(1) == dim, "nfopp: samples must be [P, ", dim, "]");
   TORCH_CHECK(labels.numel() == samples.size(0), "nfopp: labels must be [P]");
-  c10::hip::HIPGuard guard(params.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(params.device());
   const int64_t P = samples.size(0);
   const size_t ws_bytes = nfopp_onf_train_workspace_bytes(&c, P);
   Tensor ws = at::empty({(int64_t)((ws_bytes + 3) / 4)}, params.options());
@@ -193,7 +193,7 @@ void adam_step(Tensor param, const Tensor& grad, Tensor m, Tensor v, double beta
   same_device(param, grad, "grad"); same_device(param, m, "m"); same_device(param, v, "v");
   const int64_t n = param.numel();
   TORCH_CHECK(grad.numel() >= n && m.numel() == n && v.numel() == n, "nfopp: grad / m / v must cover the ", n, " parameters");
-  c10::hip::HIPGuard guard(param.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(param.device());
   check_status(nfopp_adam_step(param.data_ptr<float>(), grad.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(), n,
                                (float)beta2, (float)omb1, (float)omb2, (float)eps, (float)step_size, (float)bc2_sqrt,
                                stream_of(param)));

@@ -144,7 +144,7 @@ class NERFOptPlanner(ContinuousPlanner):
         if positions is None:
             if self._previous_trajectory is None:
                 self._previous_trajectory = self._trajectory.detach().cpu().numpy().copy()
-            positions = self._sample_collision_checker_points(self._previous_trajectory)
+            positions = self._host_training_poses(self._previous_trajectory)
             self._previous_trajectory = self._trajectory.detach().cpu().numpy().copy()
         truth = self._calculate_truth_collision(positions)
         self._fit_step(positions, np.asarray(truth))
@@ -181,43 +181,54 @@ class NERFOptPlanner(ContinuousPlanner):
     def _calculate_predicted_collision(self, positions):
         return self._collision_model(torch.tensor(np.ascontiguousarray(positions, dtype=np.float32), device=self._device))
 
-    def _sample_collision_checker_points(self, trajectory):
-        positions = self._random_intermediate_positions_np(trajectory)
-        course_positions = self._offset_positions(positions, self._course_random_offset)
-        fine_positions = self._offset_positions(positions, self._fine_random_offset)
-        times = np.concatenate([self._collision_positions_times, np.zeros(len(fine_positions))], axis=0)
-        positions = np.concatenate([self._collision_positions, fine_positions], axis=0)
-        self._collision_positions, self._collision_positions_times = self._resample_collision_positions(positions, times)
-        return np.concatenate([course_positions, self._collision_positions,
-                               self._sample_random_field_points(self._random_field_points)], axis=0)
+    def _host_training_poses(self, previous):
+        """Training poses of one fitting step for the B = 1 drop-in planner, formed on the host because the caller's
+        collision checker is a host object (nerf:101-141; SE(2) variants constrained:49-61,173-176).  The fixtures g9 / g15 /
+        g18 replay the reference's global numpy stream, so the ORDER and SHAPES of the draws are part of the contract:
+            1. rand(N-1)                       where on each segment of the previous trajectory a pose is taken
+            2. randn(N-1, 2) [+ randn(N-1)]    "course" copies: xy noise (and heading noise for SE(2))
+            3. randn(N-1, 2) [+ randn(N-1)]    "fine" copies, appended to the retained pool
+            4. choice(len, pool size, p=w)     retained-pool resampling -- only once the candidates outnumber the pool
+            5. rand(F, 2) [+ rand(F, 1)]       uniform field poses (and headings)
+        Returns course | retained pool | field poses; the pool and its ages are kept for the next step."""
+        seg = np.random.rand(previous.shape[0] - 1).astype(np.float32)[:, None]                              # 1
+        between = previous[1:] * (np.float32(1) - seg) + previous[:-1] * seg        # plain fp32 lerp, nerf:113-117
+        course = self._jitter(between, self._course_random_offset)                                          # 2
+        fine = self._jitter(between, self._fine_random_offset)                                              # 3
+        candidates = np.concatenate([self._collision_positions, fine], axis=0)
+        ages = np.concatenate([self._collision_positions_times, np.zeros(len(fine))], axis=0)
+        keep = self._collision_point_count
+        if len(candidates) >= keep:
+            # weights sigmoid(logit) * exp(-0.03 age) + 1e-6 (nerf:122-133); sigmoid in fp32 like torch's
+            logits = self._calculate_predicted_collision(candidates).detach().cpu().numpy()[:, 0]
+            w = (np.float32(1) / (np.float32(1) + np.exp(-logits, dtype=np.float32))).astype(np.float32)
+            w = w * np.exp(-ages * 0.03) + 1e-6
+            w = w / np.sum(w)
+            with_replacement = np.count_nonzero(w > 1e-6) < keep
+            chosen = np.random.choice(len(candidates), keep, replace=with_replacement, p=w)                 # 4
+            candidates, ages = candidates[chosen], (ages + 1)[chosen]
+        self._collision_positions, self._collision_positions_times = candidates, ages
+        return np.concatenate([course, candidates, self._uniform_poses(self._random_field_points)], axis=0)  # 5
 
-    @staticmethod
-    def _random_intermediate_positions_np(trajectory):
-        """nerf:113-117 on a host copy: plain fp32 lerp with numpy draws."""
-        t = np.random.rand(trajectory.shape[0] - 1).astype(np.float32)[:, None]
-        return trajectory[1:] * (np.float32(1) - t) + trajectory[:-1] * t
+    def _jitter(self, poses, xy_sigma):
+        """Gaussian copies of poses.  2-D: a new float64 array (nerf:119-120); SE(2): an fp32 copy written in place, headings
+        with `angle_offset` (constrained:57-61) -- the dtypes differ in the reference and both are kept."""
+        if self.point_dim == 2:
+            return poses + np.random.randn(poses.shape[0], 2) * xy_sigma
+        out = poses.copy()
+        out[:, :2] = out[:, :2] + np.random.randn(out.shape[0], 2) * xy_sigma
+        out[:, 2] = out[:, 2] + np.random.randn(out.shape[0]) * self._angle_offset
+        return out
 
-    def _offset_positions(self, positions, offset):
-        return positions + np.random.randn(positions.shape[0], 2) * offset
-
-    def _resample_collision_positions(self, positions, times):
-        if len(positions) < self._collision_point_count:
-            return positions, times
-        logits = self._calculate_predicted_collision(positions).detach().cpu().numpy()[:, 0]
-        weights = (np.float32(1) / (np.float32(1) + np.exp(-logits, dtype=np.float32))).astype(np.float32)
-        weights = weights * np.exp(-times * 0.03) + 1e-6
-        weights = weights / np.sum(weights)
-        replace = np.count_nonzero(weights > 1e-6) < self._collision_point_count
-        indices = np.random.choice(len(positions), self._collision_point_count, replace=replace, p=weights)
-        times = times + 1
-        return positions[indices], times[indices]
-
-    def _sample_random_field_points(self, points_count):
-        b = self._random_sample_border
-        random_points = np.random.rand(points_count, 2)
-        random_points[:, 0] = b[0] + random_points[:, 0] * (b[1] - b[0])
-        random_points[:, 1] = b[2] + random_points[:, 1] * (b[3] - b[2])
-        return random_points
+    def _uniform_poses(self, count):
+        """`count` poses uniform over the sampling border (nerf:135-141), SE(2): + a uniform heading (constrained:173-176)."""
+        lo_x, hi_x, lo_y, hi_y = self._random_sample_border
+        xy = np.random.rand(count, 2)
+        xy[:, 0] = lo_x + xy[:, 0] * (hi_x - lo_x)
+        xy[:, 1] = lo_y + xy[:, 1] * (hi_y - lo_y)
+        if self.point_dim == 2:
+            return xy
+        return np.concatenate([xy, np.random.rand(count, 1) * 2 * np.pi], axis=1)
 
     # ---- trajectory optimisation (nerf:143-169) ------------------------------------------------------------------
     def _draw_t(self):
@@ -249,7 +260,7 @@ class NERFOptPlanner(ContinuousPlanner):
 
     def _init_collision_model(self):
         for _ in range(self._init_collision_iteration):
-            positions = self._sample_random_field_points(self._init_collision_points)
+            positions = self._uniform_poses(self._init_collision_points)
             self._optimize_collision_model(positions)
 
     def _endpoint_update(self, point, is_goal):
@@ -338,17 +349,6 @@ class ConstrainedNERFOptPlanner(NERFOptPlanner):
         self.checked_positions = Position2.from_vec(positions)
         self.truth_collision = self._collision_checker.check_collision(self.checked_positions)
         return self.truth_collision
-
-    def _offset_positions(self, positions, offset):
-        positions = positions.copy()
-        positions[:, :2] = positions[:, :2] + np.random.randn(positions.shape[0], 2) * offset
-        positions[:, 2] = positions[:, 2] + np.random.randn(positions.shape[0]) * self._angle_offset
-        return positions
-
-    def _sample_random_field_points(self, points_count):
-        random_points = super()._sample_random_field_points(points_count)
-        angles = np.random.rand(points_count, 1) * 2 * np.pi
-        return np.concatenate([random_points, angles], axis=1)
 
     def _draw_t(self):
         if self._rng == "device":

@@ -25,6 +25,20 @@ def test_library_loads_and_exports_every_header_symbol():
     assert lib.nfopp_device_count() >= 0
 
 
+def test_no_packed_fp32_op_reads_a_high_dword_into_its_low_lane():
+    """The build's own post-link check (tools/check_packed_opsel.sh), run again on the library the tests load: no gfx950
+    code object holds a v_pk_*_f32 ... op_sel form whose low lane takes a pair's high dword (wrong low
+    lanes on MI355X right behind an LDS read of the pair; replay in tools/micro/pk_opsel_lds.hip)."""
+    import subprocess
+    res = subprocess.run([os.path.join(ROOT, "tools", "check_packed_opsel.sh"), _lib.LIB_PATH], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    # the pattern the script looks for does match the offending form and not the harmless direction
+    import re as _re
+    pat = _re.compile(r"op_sel:\[[01,]*1[01,]*\]")
+    assert pat.search("v_pk_fma_f32 v[206:207], v[14:15], v[152:153], v[18:19] op_sel:[0,1,0]")
+    assert not pat.search("v_pk_fma_f32 v[206:207], v[10:11], v[152:153], v[206:207] op_sel_hi:[1,0,1]")
+
+
 def test_struct_layouts_match_header():
     import ctypes
     assert ctypes.sizeof(_lib.OnfConfigC) == 20
