@@ -77,7 +77,7 @@ __global__ __launch_bounds__(RP_THREADS) void reparam_kernel(const ReparamArgs a
   float* cmf = cdf + (N + 2);     // N+2   [0, cm, 0]
   float* lf = cmf + (N + 2);      // N+2   [l0, mid-averages, lN]
   float* li = lf + (N + 2);       // N     interpolated multipliers
-  float* red = li + N;            // 8 lane sums of the torch-order reduction
+  float* red = li + N;            // 8 lane sums of the torch-order reduction, the total, 4 wave sums (float64)
 
   float* traj = a.traj + b * N * D;
   for (int k = tid; k < N * D; k += RP_THREADS) Q[D + k] = traj[k];
@@ -114,11 +114,55 @@ __global__ __launch_bounds__(RP_THREADS) void reparam_kernel(const ReparamArgs a
     } else {
       total = torch_row_sum(cdf + 1, 1, n_el);   // scalar_inner_sum
     }
-    double run = 0.0;   // torch.cumsum on CPU: float64 accumulator, every partial rounded to fp32
+    red[8] = total;
     cdf[0] = 0.f;
-    for (int s = 1; s <= N + 1; ++s) {
-      run += (double)(cdf[s] / total);
-      cdf[s] = (float)run;
+  }
+  __syncthreads();
+  // torch.cumsum on CPU: a float64 accumulator walks the fp32 quotients in order and every partial sum is rounded to fp32.
+  // The quotients are multiples of 2^(e-23) with e their smallest exponent and every partial sum stays below 2, so if the
+  // smallest non-zero quotient is at least 2^-29 EVERY sum of a subset of them is exactly representable in float64: the
+  // additions are exact, their order does not matter, and a parallel scan returns the sequential loop's partial sums bit
+  // for bit.  Otherwise (a segment 2^-29 of the path length, or a degenerate path) one lane walks the sequence as torch does.
+  const float total = red[8];
+  const int per = (n_el + RP_THREADS - 1) / RP_THREADS, lo_s = 1 + tid * per, hi_s = min(lo_s + per, n_el + 1);
+  float qmin = 1.0f;
+  bool ok = total > 0.0f && total < 3.0e38f;
+  for (int s2 = lo_s; s2 < hi_s; ++s2) {
+    const float q = cdf[s2] / total;
+    cdf[s2] = q;
+    if (q != 0.0f) qmin = fminf(qmin, q);
+    ok = ok && (q >= 0.0f) && (q <= 1.0f);    // (false for NaN)
+  }
+  ok = ok && qmin >= 1.862645149230957e-09f;   // 2^-29
+  const bool exact = __syncthreads_and(ok);
+  if (exact) {
+    double part = 0.0;
+    for (int s2 = lo_s; s2 < hi_s; ++s2) part += (double)cdf[s2];
+    // exclusive offsets of the per-thread sums: wave scan, then the wave totals through LDS (as doubles in `red2`)
+    double incl = part;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    float* r8 = red + 9;
+    if (reinterpret_cast<size_t>(r8) & 7) r8 += 1;        // 8-byte aligned slot for the four wave sums
+    double* red2 = reinterpret_cast<double*>(r8);
+    if (lane == 63) red2[wave] = incl;
+    __syncthreads();
+    double off = incl - part;
+    for (int w2 = 0; w2 < wave; ++w2) off += red2[w2];
+    double run = off;
+    for (int s2 = lo_s; s2 < hi_s; ++s2) {
+      run += (double)cdf[s2];
+      cdf[s2] = (float)run;
+    }
+  } else if (tid == 0) {
+    double run = 0.0;
+    for (int s2 = 1; s2 <= N + 1; ++s2) {
+      run += (double)cdf[s2];
+      cdf[s2] = (float)run;
     }
   }
   __syncthreads();
@@ -171,7 +215,7 @@ extern "C" int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t d
   ReparamArgs a;
   a.n = n_waypoints; a.dim = dim; a.traj = traj_dev; a.start = start_dev; a.goal = goal_dev;
   a.lam = lam_dev; a.cm = cm_dev; a.u = u_dev; a.active = active_dev;
-  const size_t lds = (size_t)((n_waypoints + 2) * dim + 3 * (n_waypoints + 2) + n_waypoints + 8) * 4;
+  const size_t lds = (size_t)((n_waypoints + 2) * dim + 3 * (n_waypoints + 2) + n_waypoints + 8 + 12) * 4;
   NFOPP_REQUIRE(lds <= 160 * 1024, "trajectory too long for one workgroup's LDS (%zu bytes)", lds);
   auto kern = dim == 3 ? reparam_kernel<3> : reparam_kernel<2>;
   if (lds > 64 * 1024)

@@ -155,6 +155,23 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
   if (a.active && !a.active[b]) return;  // retired trajectory (uniform per workgroup)
 
   float* traj = a.traj + b * N * D;
+  // This thread's first waypoint (w = tid) needs two draws, two ONF records and its Adam moments from global memory.  Issued
+  // here, with the state loads, they cost ONE exposure to the memory latency instead of one per phase (the loads cannot
+  // move across the barriers by themselves).  Waypoints beyond the first pass (N > 256) load where they are used.
+  const float* tb = a.t + b * (N - 1);
+  const float* onf = a.onf + b * (N - 1) * 4;
+  float* am = a.adam_m + b * N * D;
+  float* av = a.adam_v + b * N * D;
+  float pf_t0 = 0.f, pf_t1 = 0.f, pf_m[D], pf_v[D];
+  float4 pf_o0 = {0.f, 0.f, 0.f, 0.f}, pf_o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < D; ++d) { pf_m[d] = 0.f; pf_v[d] = 0.f; }
+  if (tid < N) {
+    if (tid <= N - 2) { pf_t0 = tb[tid]; pf_o0 = reinterpret_cast<const float4*>(onf)[tid]; }
+    if (tid >= 1) { pf_t1 = tb[tid - 1]; pf_o1 = reinterpret_cast<const float4*>(onf)[tid - 1]; }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { pf_m[d] = am[tid * D + d]; pf_v[d] = av[tid * D + d]; }
+  }
   for (int k = tid; k < N * D; k += TU_THREADS) Q[D + k] = traj[k];
   if (tid < D) {
     Q[tid] = a.start[b * D + tid];
@@ -166,9 +183,8 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
   }
   __syncthreads();
 
-  // (staging t / the ONF records in LDS with the state loads measured slower, twice: round 1 and round 2)
-  const float* tb = a.t + b * (N - 1);
-  const float* onf = a.onf + b * (N - 1) * 4;
+  // (staging t / the ONF records in LDS with the state loads measured slower, twice: round 1 and round 2; round 3 keeps
+  // them in registers instead, see the prefetch above)
   float terms[NFOPP_NUM_TERMS];
 #pragma unroll
   for (int k = 0; k < NFOPP_NUM_TERMS; ++k) terms[k] = 0.f;
@@ -204,8 +220,9 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
       float g_cm = 0.f;
       const float cm_c = cm[w];
       if (w <= N - 2) {
-        const float tj = tb[w];
-        const float4 o = reinterpret_cast<const float4*>(onf)[w];
+        const bool first = w == tid;
+        const float tj = first ? pf_t0 : tb[w];
+        const float4 o = first ? pf_o0 : reinterpret_cast<const float4*>(onf)[w];
         const float cm_i = cm[w + 1] * (1.0f - tj) + cm_c * tj;
         float gamma, thl, sp;
         collision_terms(hp, o.x, cm_i, &gamma, &thl, &sp);
@@ -214,8 +231,9 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
         g_cm += tj * thl;
       }
       if (w >= 1) {
-        const float tj = tb[w - 1];
-        const float4 o = reinterpret_cast<const float4*>(onf)[w - 1];
+        const bool first = w == tid;
+        const float tj = first ? pf_t1 : tb[w - 1];
+        const float4 o = first ? pf_o1 : reinterpret_cast<const float4*>(onf)[w - 1];
         const float cm_i = cm_c * (1.0f - tj) + cm[w - 1] * tj;
         float gamma, thl, sp;
         collision_terms(hp, o.x, cm_i, &gamma, &thl, &sp);
@@ -242,16 +260,18 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
       terms[1] += dlx * dlx + dly * dly;
       if (w == N - 1) terms[1] += drx * drx + dry * dry;
       if (w <= N - 2) {
-        const float tj = tb[w];
-        const float4 o = reinterpret_cast<const float4*>(onf)[w];
+        const bool first = w == tid;
+        const float tj = first ? pf_t0 : tb[w];
+        const float4 o = first ? pf_o0 : reinterpret_cast<const float4*>(onf)[w];
         float gamma, thl, sp;
         collision_terms(hp, o.x, 0.0f, &gamma, &thl, &sp);
         terms[2] += sp;
         gx += tj * (gamma * o.y); gy += tj * (gamma * o.z);
       }
       if (w >= 1) {
-        const float tj = tb[w - 1];
-        const float4 o = reinterpret_cast<const float4*>(onf)[w - 1];
+        const bool first = w == tid;
+        const float tj = first ? pf_t1 : tb[w - 1];
+        const float4 o = first ? pf_o1 : reinterpret_cast<const float4*>(onf)[w - 1];
         float gamma, thl, sp;
         collision_terms(hp, o.x, 0.0f, &gamma, &thl, &sp);
         const float omt = 1.0f - tj;
@@ -265,8 +285,6 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
   // g <- H^-1 g with the band of the reference's fp32 inverse (nerf:151), then Adam (torch single-tensor path).
   // Taps k = 0 .. 2W in ascending order for every waypoint; out-of-range taps meet a zero band entry and a zero-padded
   // gradient row, so the sum is the same fp32 chain as over the valid taps alone.
-  float* am = a.adam_m + b * N * D;
-  float* av = a.adam_v + b * N * D;
   for (int w = tid; w < N; w += TU_THREADS) {
     float acc[D];
 #pragma unroll
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(TU_THREADS, NFOPP_K2_WAVES) void traj_update_kernel
     // optimiser state is independent of the band product: issue its loads before the taps
     float m_in[D], v_in[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) { m_in[d] = am[w * D + d]; v_in[d] = av[w * D + d]; }
+    for (int d = 0; d < D; ++d) { m_in[d] = w == tid ? pf_m[d] : am[w * D + d]; v_in[d] = w == tid ? pf_v[d] : av[w * D + d]; }
     const bool interior = w >= a.interior_lo && w < a.interior_hi;
     const float* gj = GP + w * D;   // row w - W of the unpadded gradient
     if (interior || a.bnd_in_lds) {

@@ -16,8 +16,9 @@ from nfopp import _lib  # noqa: E402
 def bind(path):
     lib = ctypes.CDLL(path)
     for name, (res, args) in _lib._SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = res, args
+        if hasattr(lib, name):          # (a variant built before an ABI addition lacks the new symbols)
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
     return lib
 
 
@@ -57,6 +58,24 @@ if KERNEL == "k2":
         rc = lib.nfopp_traj_update(hp, e.B, e.N, e.D, _lib.ptr(e.traj), _lib.ptr(e.start), _lib.ptr(e.goal), _lib.ptr(e.lam),
                                    _lib.ptr(e.cm), _lib.ptr(e.adam_m), _lib.ptr(e.adam_v), _lib.ptr(e.t), _lib.ptr(e.onf_out),
                                    _lib.ptr(e.hinv_band), e.half_width, e.interior[0], e.interior[1], None, None, _lib.stream_ptr())
+        assert rc == 0, lib.nfopp_last_error()
+    out = {k: engs[k].traj for k in libs}
+
+if KERNEL == "k3":      # arc-length reparametrisation
+    from nfopp.engine import TrajectoryEngine, TrajectoryHyper
+    hyper = TrajectoryHyper(100, 5, 100, 0.1, 1e-3, 1, 10, 100, 5e-2, (0.9, 0.9), 1e-8, (0, 100, 0, 100))
+    engs = {}
+    walk = torch.cumsum(torch.rand(B, N, 3, device="cuda") * torch.tensor([0.5, 0.5, 0.05], device="cuda"), dim=1)
+    for k in libs:
+        e = TrajectoryEngine(onf, B, N, 3, hyper, 0.5, "cuda")
+        e.traj.copy_(walk)
+        e.set_endpoints(walk[:, 0].cpu().numpy(), walk[:, -1].cpu().numpy())
+        engs[k] = e
+
+    def run(lib, o, _libs=libs, _engs=engs):   # noqa: F811
+        e = _engs["product" if lib is _libs["product"] else "variant"]
+        rc = lib.nfopp_reparametrize(e.B, e.N, e.D, _lib.ptr(e.traj), _lib.ptr(e.start), _lib.ptr(e.goal), _lib.ptr(e.lam),
+                                     _lib.ptr(e.cm), _lib.ptr(e.u), None, _lib.stream_ptr())
         assert rc == 0, lib.nfopp_last_error()
     out = {k: engs[k].traj for k in libs}
 
