@@ -221,12 +221,27 @@ __device__ __forceinline__ void step6(f32x16& acc, const u32x4& ah, const u32x4&
   } else {
     acc = mfma32(al, b[0], acc);
   }
+#if defined(X32_GROUP2)   /* development A/B: MFMAs in pairs, the work of both slots behind the pair */
+  acc = mfma32(ah, b[2], acc); work(ic<SLOT0 + 0>{}); work(ic<SLOT0 + 1>{}); __builtin_amdgcn_sched_barrier(0);
+  acc = mfma32(am, b[1], acc);
+  acc = mfma32(am, b[0], acc); work(ic<SLOT0 + 2>{}); work(ic<SLOT0 + 3>{}); __builtin_amdgcn_sched_barrier(0);
+  acc = mfma32(ah, b[1], acc);
+  acc = mfma32(ah, b[0], acc); work(ic<SLOT0 + 4>{}); work(ic<SLOT0 + 5>{}); __builtin_amdgcn_sched_barrier(0);
+#elif defined(X32_NO_FENCE)   /* development A/B: hipcc places the work items */
+  work(ic<SLOT0 + 0>{});
+  acc = mfma32(ah, b[2], acc); work(ic<SLOT0 + 1>{});
+  acc = mfma32(am, b[1], acc); work(ic<SLOT0 + 2>{});
+  acc = mfma32(am, b[0], acc); work(ic<SLOT0 + 3>{});
+  acc = mfma32(ah, b[1], acc); work(ic<SLOT0 + 4>{});
+  acc = mfma32(ah, b[0], acc); work(ic<SLOT0 + 5>{});
+#else
   work(ic<SLOT0 + 0>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(ah, b[2], acc); work(ic<SLOT0 + 1>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(am, b[1], acc); work(ic<SLOT0 + 2>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(am, b[0], acc); work(ic<SLOT0 + 3>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(ah, b[1], acc); work(ic<SLOT0 + 4>{}); __builtin_amdgcn_sched_barrier(0);
   acc = mfma32(ah, b[0], acc); work(ic<SLOT0 + 5>{}); __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 // one instruction of the exact pair split (11 per pair): x0, x1 -> one word of each level
