@@ -279,11 +279,10 @@ __device__ __forceinline__ void eval_item(EvalState& s, const f32x4& tw, float u
   if constexpr (U == 7) s.v = __builtin_amdgcn_sinf(s.v);
 }
 
-#ifndef X32_THREADS
-#define X32_THREADS 512   /* development A/B: 256 = one wave per SIMD (512 registers a wave) */
-#endif
-constexpr int XT = X32_THREADS;
-constexpr int CH = (XT / 64) * 32;   // samples per workgroup pass: 8 waves x one 32-sample tile
+// Workgroup shapes: XT = 512 threads (two waves per SIMD, 256 samples per pass) fills the chip at scale; XT = 256 (one wave per
+// SIMD, 128 samples per pass) takes the launches that cannot give every CU a 256-sample chunk: twice the CUs take part and a
+// wave alone on its SIMD finishes its tile in about half the time (B = 1 drop-in latency).  A tile's arithmetic does not
+// depend on the shape, so results are bit-identical either way (sharding-independent).
 
 // Development build (make EXTRA=-DX32_PHASE_PROFILE): waves 0 and 4 of every workgroup accumulate clock ticks per phase of the
 // chunk loop; launch_t prints the shares every tenth launch of the mode-0 kernel (synchronous, stderr).
@@ -298,11 +297,12 @@ constexpr int CH = (XT / 64) * 32;   // samples per workgroup pass: 8 waves x on
 #define X32_TICK(SLOT)
 #endif
 
-template <int NKB, int MODE>
+template <int NKB, int MODE, int XT>
 __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelArgs a, const u32x4* __restrict__ img,
                                                          const u32x4* __restrict__ blob) {
   using C = Cfg<NKB>;
   constexpr bool FWD_ONLY = MODE == 2;
+  constexpr int CH = (XT / 64) * 32;   // samples per workgroup pass: one 32-sample tile per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   {   // image -> LDS, four 16-byte pieces per thread in flight
     constexpr int N16 = IMG_BYTES / 16;
@@ -805,11 +805,12 @@ static int buffers_for_stream(size_t bytes, hipStream_t stream, void** out, Slot
   return NFOPP_OK;
 }
 
-template <int NKB, int MODE>
-static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
+template <int NKB, int MODE, int XT>
+static int launch_shape(const OnfKernelArgs& a, hipStream_t stream) {
   using C = Cfg<NKB>;
+  constexpr int CH = (XT / 64) * 32;
   static bool attr_set[MAX_DEVICES] = {};
-  auto kern = onf_x32_kernel<NKB, MODE>;
+  auto kern = onf_x32_kernel<NKB, MODE, XT>;
   int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), IMG_BYTES, attr_set);
   if (rc != NFOPP_OK) return rc;
   void* buf = nullptr;
@@ -861,6 +862,15 @@ static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(XT), IMG_BYTES, stream, a, (const u32x4*)img, (const u32x4*)blob);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;
+}
+
+template <int NKB, int MODE>
+static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
+#ifdef X32_THREADS   /* development A/B: one shape at every size */
+  return launch_shape<NKB, MODE, X32_THREADS>(a, stream);
+#else
+  return a.n_points < (long long)query_cus() * 256 ? launch_shape<NKB, MODE, 256>(a, stream) : launch_shape<NKB, MODE, 512>(a, stream);
+#endif
 }
 
 }  // namespace x32

@@ -29,7 +29,7 @@ for arg in sys.argv[1:]:
     variants[name] = (lib, int(mp) if mp else 1)
 torch.manual_seed(0)
 onf = nfopp.ONF(0.0, 10.0, use_cos=True, use_normal_init=True, bias=True, angle_encoding=True).to("cuda")
-B, N = 4096, 256
+B, N = int(os.environ.get("AB_B", "4096")), int(os.environ.get("AB_N", "256"))
 traj = torch.rand(B, N, 3, device="cuda") * torch.tensor([100.0, 100.0, 6.0], device="cuda")
 t = torch.zeros(B, N - 1, device="cuda")
 out = {k: torch.zeros(B, N - 1, 4, device="cuda") for k in variants}
