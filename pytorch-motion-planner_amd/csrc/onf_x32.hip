@@ -214,7 +214,13 @@ __device__ __forceinline__ u32x4 lds_tr(const unsigned char* lds, int byte0, int
 // FIRST: the accumulator starts here -- the first product takes a literal zero as its C operand (no register zeroing)
 template <int SLOT0, bool FIRST = false, class W>
 __device__ __forceinline__ void step6(f32x16& acc, const u32x4& ah, const u32x4& am, const u32x4& al, const u32x4 (&b)[3],
-                                      W&& work) {
+                                      W&& work_in) {
+#ifdef X32_ABL_NOWORK   /* timing-only ablation (results wrong): the MFMA steps without the hooked vector work */
+  auto work = [](auto) {};
+  (void)work_in;
+#else
+  auto& work = work_in;
+#endif
   if constexpr (FIRST) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     acc = mfma32(al, b[0], zero);
@@ -365,7 +371,11 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
   const __amdgpu_buffer_rsrc_t blob_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(blob), 0, (int)C::BLOB_BYTES, 0x00020000);
   auto lo_frag = [&](int step) __attribute__((always_inline)) {
+#ifdef X32_ABL_NOLO   /* timing-only ablation (results wrong): no third-level loads */
+    return u32x4{(unsigned)step, lane16, 0u, 0u};
+#else
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane16, step * 1024, 0));
+#endif
   };
 
   const long long n_work = work_points(a);

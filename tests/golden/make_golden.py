@@ -767,6 +767,12 @@ def g16_grid_checker():
     from neural_field_optimal_planner.collision_checker import CollisionChecker
     with open(os.path.join(REF, "notebooks", "onf_planner_image_map.ipynb")) as f:
         cell = "".join(json.load(f)["cells"][2]["source"])
+    # the cell is executed: pin its content (the reference tree is untrusted input; the fixture is only regenerated from the
+    # very text these labels were made from)
+    import hashlib
+    digest = hashlib.sha256(cell.encode()).hexdigest()
+    if digest != "d54fd758d908a4202f4d8899fcd433fb51cd10cb44177ca37c25b5fce7c70fc5":
+        raise RuntimeError("notebooks/onf_planner_image_map.ipynb cell 2 changed (sha256 %s): review it before executing" % digest)
     ns = {"np": np, "dataclass": dataclass, "CollisionChecker": CollisionChecker}
     exec(compile(cell, "onf_planner_image_map.ipynb#cell2", "exec"), ns)
     grid = corridor_grid()

@@ -153,3 +153,32 @@ def test_cached_weight_image_follows_the_parameters():
     after = onf.forward_with_grad(x)
     torch.cuda.synchronize()
     assert not torch.equal(after, base)
+
+
+@pytest.mark.parametrize("use_cos,angle,bias", [(True, True, True), (True, False, True), (False, True, False), (False, False, True),
+                                                (True, False, False)])
+def test_every_feature_dimension_on_every_matrix_path_vs_oracle(use_cos, angle, bias):
+    """The four feature dimensions the kernels are instantiated for (F = 220 / 200 / 120 / 100) with and without the encoding
+    bias -- the golden networks cover only 220 and 100 -- on the three matrix paths, both workgroup shapes of the 32x32 kernel
+    (ragged counts below and above one 256-sample chunk per CU), against the numpy oracle (fp32 gates of test_gpu_parity.py)."""
+    torch.random.manual_seed(11)
+    onf = nfopp.ONF(0.4, 2.5, use_cos=use_cos, use_normal_init=True, bias=bias, angle_encoding=angle).to("cuda")
+    cfg = orc.OnfConfig(0.4, 2.5, use_cos, bias, angle)
+    flat = onf.flat_parameters.cpu().numpy()
+    rng = np.random.default_rng(3)
+    d = 3 if angle else 2
+    for n in (1, 33, 300, 4099, 70001):
+        x = rng.uniform(-4, 6, (n, d)).astype(F32)
+        if angle:
+            x[:, 2] = rng.uniform(-3.3, 3.3, n)
+        lo, go = orc.onf_forward_grad(flat, cfg, x)
+        res = {}
+        for path in (1, 2, 0):
+            o, l = _eval(onf, x, path)
+            assert gc.scaled_err(o[:, 0], lo) < 1e-5, (path, n)
+            assert gc.scaled_err(o[:, 1:1 + d], go) < 5e-5, (path, n)
+            assert np.array_equal(l, o[:, 0]) or gc.scaled_err(l, o[:, 0]) < 1e-6
+            if d == 2:
+                assert np.all(o[:, 3] == 0)
+            res[path] = o
+        assert gc.scaled_err(res[1], res[0]) < 3e-6 and gc.scaled_err(res[2], res[0]) < 3e-6
