@@ -24,7 +24,7 @@ for name in ("fetch","write","sq1","sq2","sq3"):
     agg = collections.defaultdict(list)
     for f in files:
         for row in csv.DictReader(open(f)):
-            if "onf_x32_kernel<14, 0>" in row.get("Kernel_Name",""):
+            if "onf_x32_kernel<14, 0" in row.get("Kernel_Name",""):
                 agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k,v in agg.items():
         out[k] = sum(v)/len(v)
