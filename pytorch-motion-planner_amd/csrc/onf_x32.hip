@@ -303,12 +303,58 @@ __device__ __forceinline__ void eval_item(EvalState& s, const f32x4& tw, float u
 #define X32_TICK(SLOT)
 #endif
 
-template <int NKB, int MODE, int XT>
+// One MFMA step for NT point tiles that share the weight fragments: the six partial products in the order of step6, each
+// issued for tile 0 .. NT-1 in turn (independent accumulators alternate on the matrix pipe); WORK(slot) runs behind MFMA
+// number slot - SLOT0 (6 NT slots per step).
+template <int NT, int SLOT0, bool FIRST, class W>
+__device__ __forceinline__ void stepN(f32x16 (&acc)[NT], const u32x4& ah, const u32x4& am, const u32x4& al,
+                                      const u32x4 (&b)[NT][3], W&& work) {
+  sfor<0, 6>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    sfor<0, NT>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      const u32x4& a_ = p == 0 ? al : ((p == 2 || p == 3) ? am : ah);
+      const u32x4& b_ = b[T][p == 1 ? 2 : ((p == 2 || p == 4) ? 1 : 0)];
+      if constexpr (FIRST && p == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[T] = mfma32(a_, b_, zero);
+      } else {
+        acc[T] = mfma32(a_, b_, acc[T]);
+      }
+      work(ic<SLOT0 + p * NT + T>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+}
+
+// one instruction of the evaluation of a feature of ANY kind (positional / angle / ones / pad; the arithmetic of
+// feature_any in the kernel): 12 per feature.  isa != 0: angle feature (angle_encoder.py:16); is_one: the ones feature.
+struct EvalAnyState { float arg, za, t, j, r, v; };
+template <int U>
+__device__ __forceinline__ void eval_any_item(EvalAnyState& s, const f32x4& tw, float isa, float ux, float uy, float th, bool is_one) {
+  if constexpr (U == 0) s.arg = fmaf(tw.y, uy, tw.z);
+  if constexpr (U == 1) s.arg = fmaf(tw.x, ux, s.arg);
+  if constexpr (U == 2) s.za = th + tw.z;
+  if constexpr (U == 3) s.za = s.za * tw.x;
+  if constexpr (U == 4) s.arg = isa != 0.0f ? s.za : s.arg;
+  if constexpr (U == 5) s.t = fmaf(s.arg, 0.159154943f, 12582912.0f);
+  if constexpr (U == 6) s.j = s.t - 12582912.0f;
+  if constexpr (U == 7) s.r = fmaf(s.j, -6.28318548202514648f, s.arg);
+  if constexpr (U == 8) s.r = fmaf(s.j, 1.74845553e-07f, s.r);
+  if constexpr (U == 9) s.v = fmaf(s.r, 0.159154943f, tw.w);
+  if constexpr (U == 10) s.v = __builtin_amdgcn_sinf(s.v);
+  if constexpr (U == 11) s.v = is_one ? 1.0f : s.v;
+}
+
+// NT = 32-sample tiles per wave.  Shapes in use (x32::launch_t): <512 threads, NT 1> two waves per SIMD; <256, 2> one wave
+// per SIMD with two tiles sharing every weight fragment (half the LDS / L2 fragment traffic per sample, two independent
+// accumulation and hook chains in one stream); <256, 1> for small launches.  A tile's arithmetic is the same in all of them.
+template <int NKB, int MODE, int XT, int NT>
 __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelArgs a, const u32x4* __restrict__ img,
                                                          const u32x4* __restrict__ blob) {
   using C = Cfg<NKB>;
   constexpr bool FWD_ONLY = MODE == 2;
-  constexpr int CH = (XT / 64) * 32;   // samples per workgroup pass: one 32-sample tile per wave
+  constexpr int CH = (XT / 64) * 32 * NT;   // samples per workgroup pass: NT 32-sample tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   {   // image -> LDS, four 16-byte pieces per thread in flight
     constexpr int N16 = IMG_BYTES / 16;
@@ -390,103 +436,141 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
   // at the end of a chunk, on into the first steps of the next
   u32x4 fl[4];
   fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
-  // Samples.  Both lane halves of a wave need the wave's 32 poses, so forming them in all 64 lanes does every draw,
-  // interpolation and normalisation twice.  Instead every OTHER chunk the lower half forms this chunk's poses and the
-  // upper half the next chunk's, and the halves exchange them (5 cross-half moves): the sampling arithmetic runs once
-  // per pose.  (Each pose is still formed by exactly one lane, with the arithmetic of load_point: same bits.)
+  // Samples.  Both lane halves of a wave need each tile's 32 poses, so forming them in all 64 lanes would do every draw,
+  // interpolation and normalisation twice.  Each pose is formed by exactly ONE lane (the arithmetic of load_point: same
+  // bits) and the halves exchange (5 cross-half moves).  NT = 2: the lower half forms tile 0's poses, the upper half tile
+  // 1's.  NT = 1: every OTHER chunk the lower half forms this chunk's poses and the upper half the next chunk's.
   float nux = 0.f, nuy = 0.f, nth = 0.f;
   long long npidx = 0;
   bool have_next = false;
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    float ux, uy, th;
-    long long pidx;
+    float ux[NT], uy[NT], th[NT];
+    long long pidx[NT];
     // table bases: opaque per chunk, so that (base + small constant) stays an immediate offset of the LDS read instead
     // of one hoisted register per constant
     asm volatile("" : "+v"(ftl), "+v"(ftdl), "+v"(isl), "+v"(w3al), "+v"(w3ll), "+v"(fin_rel));
-    if (have_next) {
-      ux = nux; uy = nuy; th = nth; pidx = npidx;
+    if (NT == 1 && have_next) {
+      ux[0] = nux; uy[0] = nuy; th[0] = nth; pidx[0] = npidx;
       have_next = false;
     } else {
       float x, y, ang;
-      const long long mine = chunk + (g ? (long long)gridDim.x : 0);   // past the last chunk: padding lanes (nothing stored)
-      const long long row = load_point(a, n_work, mine * CH + wave * 32 + j, 0, x, y, ang);
+      // NT = 1: this chunk (lower half) / the next one (upper half; past the last chunk: padding lanes, nothing stored)
+      const long long p = NT == 1 ? (chunk + (g ? (long long)gridDim.x : 0)) * CH + wave * 32 + j : chunk * CH + wave * 64 + lane;
+      const long long row = load_point(a, n_work, p, 0, x, y, ang);
       const float sx = (x - geo.mean) / geo.sigma, sy = (y - geo.mean) / geo.sigma;
       const int rlo = (int)row, rhi = (int)(row >> 32);
       const float ox = __shfl_xor(sx, 32), oy = __shfl_xor(sy, 32), oa = __shfl_xor(ang, 32);
       const int olo = __shfl_xor(rlo, 32), ohi = __shfl_xor(rhi, 32);
       const long long orow = ((long long)ohi << 32) | (unsigned)olo;
-      ux = g ? ox : sx; uy = g ? oy : sy; th = g ? oa : ang; pidx = g ? orow : row;
-      nux = g ? sx : ox; nuy = g ? sy : oy; nth = g ? ang : oa; npidx = g ? row : orow;
-      have_next = true;
+      ux[0] = g ? ox : sx; uy[0] = g ? oy : sy; th[0] = g ? oa : ang; pidx[0] = g ? orow : row;      // the lower half's poses
+      if constexpr (NT == 2) {
+        ux[NT - 1] = g ? sx : ox; uy[NT - 1] = g ? sy : oy; th[NT - 1] = g ? ang : oa; pidx[NT - 1] = g ? row : orow;
+      } else {
+        nux = g ? sx : ox; nuy = g ? sy : oy; nth = g ? ang : oa; npidx = g ? row : orow;
+        have_next = true;
+      }
     }
     u32x4 fh[2], fm[2];   // hi / mid fragments: this step and the next
 
     // generic evaluation of one input feature (any kind), used for the first block and the angle / ones / pad blocks
-    auto feature_any = [&](auto special_c, int kb, int e) __attribute__((always_inline)) {
+    auto feature_any = [&](auto special_c, int T, int kb, int e) __attribute__((always_inline)) {
       constexpr bool SPECIAL = decltype(special_c)::value;   // the block may hold angle / ones / pad positions
       const int off = 256 * kb + 128 * (e >> 2) + 16 * (e & 3);
       const f32x4 tw = lds128f(lds, ftl + off);
-      float arg = fmaf(tw.x, ux, fmaf(tw.y, uy, tw.z));
+      float arg = fmaf(tw.x, ux[T], fmaf(tw.y, uy[T], tw.z));
       if constexpr (SPECIAL) {
         const float isa = *reinterpret_cast<const float*>(lds + isl + (off >> 2));
-        const float za = (th + tw.z) * tw.x;
+        const float za = (th[T] + tw.z) * tw.x;
         arg = isa != 0.0f ? za : arg;
       }
       const float v = sin_halfturns_hw(arg, tw.w);
       if constexpr (SPECIAL) return (16 * kb + 8 * (e >> 2) + (e & 3)) == fin_rel ? 1.0f : v;
       else return v;
     };
-    auto features_upfront = [&](auto special_c, int kb, u32x4 (&out)[3]) __attribute__((always_inline)) {
+    auto features_upfront = [&](auto special_c, int kb, u32x4 (&out)[NT][3]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) split_pair(feature_any(special_c, kb, 2 * p), feature_any(special_c, kb, 2 * p + 1), out, p);
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          split_pair(feature_any(special_c, T, kb, 2 * p), feature_any(special_c, T, kb, 2 * p + 1), out[T], p);
     };
 
     X32_TICK(0)   // sampling
     // ================================================================ L1: a1 = W1ext in
-    f32x16 acc1[4];
+    f32x16 acc1[4][NT];
     {
       int w1f[2][2];
       bases_w1f(w1f);
       // (the mid image's offset plus a tile offset does not fit the 16-bit immediate of an LDS read: its own bases)
       int w1m[2][2] = {{w1f[0][0] + O_W1M, w1f[0][1] + O_W1M}, {w1f[1][0] + O_W1M, w1f[1][1] + O_W1M}};
       X32_OPAQUE2(w1m);
-      u32x4 bA[3], bB[3];
+      u32x4 bA[NT][3], bB[NT][3];
       features_upfront(std::false_type{}, 0, bA);
-      // hooked preparation of the NEXT block's fragments: 4 pairs x (16 evaluation + 11 split) instructions, 5 per slot.
-      // Schedule (work item w): E0 E1 S0 E2 S1 E3 S2 S3; table entries of pair p+1 are loaded at the start of E(p).
+      // hooked preparation of the NEXT block's fragments: per tile 4 pairs x (16 evaluation + 11 split) instructions, 5 per
+      // slot, the tiles' items alternating.  Schedule of a tile (item w): E0 E1 S0 E2 S1 E3 S2 S3; the table entries of
+      // pair p+1 (shared by the tiles) are loaded at the start of E(p).
       f32x4 tw[2][2];
-      float fv[8];
-      EvalState es[2];
-      SplitState ss;
+      float fv[NT][8];
+      EvalState es[NT][2];
+      SplitState ss[NT];
       int nxt_ft = 0;   // table byte address of the block being prepared
       auto load_pair = [&](int p) __attribute__((always_inline)) {
         const int off = nxt_ft + 128 * ((2 * p) >> 2) + 16 * ((2 * p) & 3);
         tw[p & 1][0] = lds128f(lds, off);
         tw[p & 1][1] = lds128f(lds, off + 16);
       };
-      auto l1_item = [&](auto wc, u32x4 (&out)[3]) __attribute__((always_inline)) {
-        constexpr int w = decltype(wc)::value;
+      auto l1_item = [&](auto wc, u32x4 (&out)[NT][3]) __attribute__((always_inline)) {
+        constexpr int T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
         constexpr int seg = w < 16 ? 0 : w < 32 ? 1 : w < 43 ? 2 : w < 59 ? 3 : w < 70 ? 4 : w < 86 ? 5 : w < 97 ? 6 : w < 108 ? 7 : 8;
         constexpr int start[9] = {0, 16, 32, 43, 59, 70, 86, 97, 108};
         constexpr int evp[9] = {0, 1, -1, 2, -1, 3, -1, -1, -1}, spp[9] = {-1, -1, 0, -1, 1, -1, 2, 3, -1};
         constexpr int u = w - start[seg];
         if constexpr (evp[seg] >= 0) {
           constexpr int p = evp[seg], which = u & 1, st = u >> 1;
-          if constexpr (u == 0 && p < 3) load_pair(p + 1);
-          eval_item<st>(es[which], tw[p & 1][which], ux, uy);
-          if constexpr (st == 7) fv[2 * p + which] = es[which].v;
+          if constexpr (u == 0 && p < 3 && T == 0) load_pair(p + 1);
+          eval_item<st>(es[T][which], tw[p & 1][which], ux[T], uy[T]);
+          if constexpr (st == 7) fv[T][2 * p + which] = es[T][which].v;
         } else if constexpr (spp[seg] >= 0) {
           constexpr int p = spp[seg];
-          split_item<u>(ss, fv[2 * p], fv[2 * p + 1], out, p);
+          split_item<u>(ss[T], fv[T][2 * p], fv[T][2 * p + 1], out[T], p);
         }
       };
-      // MFMA steps of block kb (fragments in bc), preparing block kb + 1 into bn when HOOK
-      auto l1_block = [&](auto hook_c, auto par_c, int kb, const u32x4 (&bc)[3], u32x4 (&bn)[3], auto first_c) __attribute__((always_inline)) {
-        constexpr bool HOOK = decltype(hook_c)::value;
+      // the same for a block that may hold angle / ones / pad positions: per tile 4 pairs x (24 evaluation + 11 split)
+      // instructions, 6 per slot; the arithmetic (and its order) is feature_any's
+      EvalAnyState eas[NT][2];
+      float isa2[2][2];
+      int nxt_is = 0, nxt_pos = 0;
+      auto load_pair_any = [&](int p) __attribute__((always_inline)) {
+        load_pair(p);
+        const int off = nxt_is + 32 * ((2 * p) >> 2) + 4 * ((2 * p) & 3);
+        const f32x2 fl2 = *reinterpret_cast<const f32x2*>(lds + off);
+        isa2[p & 1][0] = fl2.x; isa2[p & 1][1] = fl2.y;
+      };
+      auto l1_item_any = [&](auto wc, u32x4 (&out)[NT][3]) __attribute__((always_inline)) {
+        constexpr int T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
+        constexpr int seg = w < 24 ? 0 : w < 48 ? 1 : w < 59 ? 2 : w < 83 ? 3 : w < 94 ? 4 : w < 118 ? 5 : w < 129 ? 6 : w < 140 ? 7 : 8;
+        constexpr int start[9] = {0, 24, 48, 59, 83, 94, 118, 129, 140};
+        constexpr int evp[9] = {0, 1, -1, 2, -1, 3, -1, -1, -1}, spp[9] = {-1, -1, 0, -1, 1, -1, 2, 3, -1};
+        constexpr int u = w - start[seg];
+        if constexpr (evp[seg] >= 0) {
+          constexpr int p = evp[seg], which = u & 1, st = u >> 1, e = 2 * p + which;
+          if constexpr (u == 0 && p < 3 && T == 0) load_pair_any(p + 1);
+          eval_any_item<st>(eas[T][which], tw[p & 1][which], isa2[p & 1][which], ux[T], uy[T], th[T],
+                            (nxt_pos + 8 * (e >> 2) + (e & 3)) == fin_rel);
+          if constexpr (st == 11) fv[T][e] = eas[T][which].v;
+        } else if constexpr (spp[seg] >= 0) {
+          constexpr int p = spp[seg];
+          split_item<u>(ss[T], fv[T][2 * p], fv[T][2 * p + 1], out[T], p);
+        }
+      };
+      // MFMA steps of block kb (fragments in bc), preparing block kb + 1 into bn when HOOK (1: a plain block, 2: any kind)
+      auto l1_block = [&](auto hook_c, auto par_c, int kb, const u32x4 (&bc)[NT][3], u32x4 (&bn)[NT][3], auto first_c) __attribute__((always_inline)) {
+        constexpr int HOOK = decltype(hook_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;   // block 0: the accumulators start here
         constexpr int PAR = decltype(par_c)::value;   // parity of kb
         const int kq = 64 * (kb >> 1);
-        if constexpr (HOOK) { nxt_ft = ftl + 256 * (kb + 1); load_pair(0); }
+        if constexpr (HOOK == 1) { nxt_ft = ftl + 256 * (kb + 1); load_pair(0); }
+        if constexpr (HOOK == 2) { nxt_ft = ftl + 256 * (kb + 1); nxt_is = isl + 64 * (kb + 1); nxt_pos = 16 * (kb + 1); load_pair_any(0); }
         sfor<0, 4>([&](auto mtc) {
           constexpr int mt = decltype(mtc)::value;
           // this step's hi / mid were fetched one step ago; fetch the next step's (past the last block: a harmless
@@ -501,54 +585,60 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           }
           fl[(mt + 3) & 3] = lo_frag(C::S_L1 + 4 * kb + mt + 3);
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * mt, FIRST>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[mt], bc, [&](auto slot) {
-            if constexpr (HOOK) sfor<0, 5>([&](auto i) { l1_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}, bn); });
+          stepN<NT, 6 * NT * mt, FIRST>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[mt], bc, [&](auto slot) {
+            if constexpr (HOOK == 1) sfor<0, 5>([&](auto i) { l1_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}, bn); });
+            if constexpr (HOOK == 2) sfor<0, 6>([&](auto i) { l1_item_any(ic<6 * decltype(slot)::value + decltype(i)::value>{}, bn); });
           });
         });
       };
       constexpr int FS = C::FS;
       fh[0] = lds128(lds, O_W1H + w1f[0][0]); fm[0] = lds128(lds, w1m[0][0]);
-      l1_block(std::true_type{}, ic<0>{}, 0, bA, bB, std::true_type{});
-      l1_block(std::true_type{}, ic<1>{}, 1, bB, bA, std::false_type{});
+      l1_block(ic<1>{}, ic<0>{}, 0, bA, bB, std::true_type{});
+      l1_block(ic<1>{}, ic<1>{}, 1, bB, bA, std::false_type{});
 #pragma unroll 1
       for (int kp = 1; kp < FS / 2 - 1; ++kp) {
-        l1_block(std::true_type{}, ic<0>{}, 2 * kp, bA, bB, std::false_type{});
-        l1_block(std::true_type{}, ic<1>{}, 2 * kp + 1, bB, bA, std::false_type{});
+        l1_block(ic<1>{}, ic<0>{}, 2 * kp, bA, bB, std::false_type{});
+        l1_block(ic<1>{}, ic<1>{}, 2 * kp + 1, bB, bA, std::false_type{});
       }
-      l1_block(std::true_type{}, ic<0>{}, FS - 2, bA, bB, std::false_type{});
-      l1_block(std::false_type{}, ic<1>{}, FS - 1, bB, bA, std::false_type{});
-      // blocks with angle / ones / pad features: evaluated up front
+      l1_block(ic<1>{}, ic<0>{}, FS - 2, bA, bB, std::false_type{});
+      // blocks FS .. NKB-1 can hold angle / ones / pad features: each is prepared behind the block in front of it
+      l1_block(ic<2>{}, ic<1>{}, FS - 1, bB, bA, std::false_type{});
       sfor<FS, NKB>([&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
-        features_upfront(std::true_type{}, kb, bA);
-        l1_block(std::false_type{}, ic<(kb & 1)>{}, kb, bA, bB, std::false_type{});
+        constexpr int HK2 = kb + 1 < NKB ? 2 : 0;
+        if constexpr ((kb - FS) % 2 == 0) l1_block(ic<HK2>{}, ic<(kb & 1)>{}, kb, bA, bB, std::false_type{});
+        else l1_block(ic<HK2>{}, ic<(kb & 1)>{}, kb, bB, bA, std::false_type{});
       });
     }
     X32_TICK(1)   // L1
-    const float skipv = acc1[3][0];   // position 100 = tile 3, g = 1, register 0: W3b . in + b3 (lanes g = 1)
+    float skipv[NT];   // position 100 = tile 3, g = 1, register 0: W3b . in + b3 (lanes g = 1)
+#pragma unroll
+    for (int T = 0; T < NT; ++T) skipv[T] = acc1[3][T][0];
 
     // ================================================================ L2: a2 = W2ext relu(a1)
-    f32x16 acc2[4];
-    unsigned m1w[2] = {0u, 0u};   // [a1 > 0]: block kb, element e -> word kb >> 2, pushed from the low end in order
+    f32x16 acc2[4][NT];
+    unsigned m1w[NT][2];   // [a1 > 0]: block kb, element e -> word kb >> 2, pushed from the low end in order
+#pragma unroll
+    for (int T = 0; T < NT; ++T) m1w[T][0] = m1w[T][1] = 0u;
     int w2f[2];
     bases_w2f(w2f);
     {
-      u32x4 bb[2][3];
-      float hv[2];
-      SplitState ss;
-      // relu + sign + split of one pair of block kb: 6 + 11 instructions
-      auto h1_item = [&](auto kbc, auto wc, u32x4 (&out)[3]) __attribute__((always_inline)) {
-        constexpr int kb = decltype(kbc)::value, w = decltype(wc)::value;
+      u32x4 bb[2][NT][3];
+      float hv[NT][2];
+      SplitState ss[NT];
+      // relu + sign + split of one pair of block kb: 6 + 11 instructions per tile, the tiles' items alternating
+      auto h1_item = [&](auto kbc, auto wc, u32x4 (&out)[NT][3]) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value, T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
         if constexpr (w < 68) {
           constexpr int p = w / 17, u = w % 17, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p;
-          if constexpr (u == 0) hv[0] = relu1(acc1[t][r0]);
-          if constexpr (u == 1) hv[1] = relu1(acc1[t][r0 + 1]);
-          if constexpr (u == 2) m1w[kb >> 2] = __builtin_amdgcn_alignbit(m1w[kb >> 2], 0u - __float_as_uint(hv[0]), 31);
-          if constexpr (u == 3) m1w[kb >> 2] = __builtin_amdgcn_alignbit(m1w[kb >> 2], 0u - __float_as_uint(hv[1]), 31);
-          if constexpr (u >= 4 && u < 15) split_item<u - 4>(ss, hv[0], hv[1], out, p);
+          if constexpr (u == 0) hv[T][0] = relu1(acc1[t][T][r0]);
+          if constexpr (u == 1) hv[T][1] = relu1(acc1[t][T][r0 + 1]);
+          if constexpr (u == 2) m1w[T][kb >> 2] = __builtin_amdgcn_alignbit(m1w[T][kb >> 2], 0u - __float_as_uint(hv[T][0]), 31);
+          if constexpr (u == 3) m1w[T][kb >> 2] = __builtin_amdgcn_alignbit(m1w[T][kb >> 2], 0u - __float_as_uint(hv[T][1]), 31);
+          if constexpr (u >= 4 && u < 15) split_item<u - 4>(ss[T], hv[T][0], hv[T][1], out[T], p);
         }
       };
-      sfor<0, 68>([&](auto w) { h1_item(ic<0>{}, w, bb[0]); });
+      sfor<0, 68 * NT>([&](auto w) { h1_item(ic<0>{}, w, bb[0]); });
       sfor<0, HK>([&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
         const int kx = kb << 5;
@@ -566,7 +656,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           }
           fl[(mt + 3) & 3] = lo_frag(C::S_L2 + 4 * kb + mt + 3);
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * mt, kb == 0>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+          stepN<NT, 6 * NT * mt, kb == 0>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, 3>([&](auto i) { h1_item(ic<kb + 1>{}, ic<3 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
@@ -577,56 +667,61 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
     X32_TICK(2)   // L2
     if constexpr (FWD_ONLY) {
       // the summation order of the full kernel (two chains over the element parity, blocks in order): same logits bit for bit
-      float lgs[2] = {0.0f, 0.0f};
-      sfor<0, HK>([&](auto kbc) {
-        constexpr int kb = decltype(kbc)::value;
-        const f32x4 w3f[2] = {lds128f(lds, w3al + 64 * kb), lds128f(lds, w3al + 64 * kb + 32)};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) lgs[e & 1] = fmaf(w3f[e >> 2][e & 3], relu1(acc2[kb >> 1][8 * (kb & 1) + e]), lgs[e & 1]);
-      });
-      float lg = lgs[0] + lgs[1] + (g == 1 ? skipv : 0.0f);
-      lg += __shfl_xor(lg, 32);
-      if (g == 0 && pidx < a.n_points) *reinterpret_cast<f32x4*>(a.out4 + pidx * 4) = f32x4{lg, 0.f, 0.f, 0.f};
+      for (int T = 0; T < NT; ++T) {
+        float lgs[2] = {0.0f, 0.0f};
+        sfor<0, HK>([&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value;
+          const f32x4 w3f[2] = {lds128f(lds, w3al + 64 * kb), lds128f(lds, w3al + 64 * kb + 32)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) lgs[e & 1] = fmaf(w3f[e >> 2][e & 3], relu1(acc2[kb >> 1][T][8 * (kb & 1) + e]), lgs[e & 1]);
+        });
+        float lg = lgs[0] + lgs[1] + (g == 1 ? skipv[T] : 0.0f);
+        lg += __shfl_xor(lg, 32);
+        if (g == 0 && pidx[T] < a.n_points) *reinterpret_cast<f32x4*>(a.out4 + pidx[T] * 4) = f32x4{lg, 0.f, 0.f, 0.f};
+      }
       fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
       continue;
     }
 
     // ================================================================ L2^T: W2ext^T dh2,  dh2 = W3a [a2 > 0]; the logit on the way
-    f32x16 accd[4];
-    float lgs[2] = {0.0f, 0.0f};
+    f32x16 accd[4][NT];
+    float lgs[NT][2];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) lgs[T][0] = lgs[T][1] = 0.0f;
     int t2[2][2];
     bases_tr(std::false_type{}, t2);
     {
-      u32x4 bb[2][3];
+      u32x4 bb[2][NT][3];
       f32x4 w3f[2];     // fp32 W3a of the block's 8 positions
       u32x4 w3c[3];     // its pre-split levels, B-fragment order
-      float hv[2];
-      unsigned mk[2];
+      float hv[NT][2];
+      unsigned mk[NT][2];
       auto dh2_load = [&](int kb) __attribute__((always_inline)) {
         w3f[0] = lds128f(lds, w3al + 64 * kb); w3f[1] = lds128f(lds, w3al + 64 * kb + 32);
         w3c[0] = lds128(lds, w3ll + 96 * kb); w3c[1] = lds128(lds, w3ll + 96 * kb + 16); w3c[2] = lds128(lds, w3ll + 96 * kb + 32);
       };
-      // one pair of block kb: relu, sign mask, logit terms, masked level words: 12 instructions
-      auto dh2_item = [&](auto kbc, auto wc, u32x4 (&out)[3]) __attribute__((always_inline)) {
-        constexpr int kb = decltype(kbc)::value, w = decltype(wc)::value;
+      // one pair of block kb: relu, sign mask, logit terms, masked level words: 12 instructions per tile, tiles alternating
+      auto dh2_item = [&](auto kbc, auto wc, u32x4 (&out)[NT][3]) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value, T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
         if constexpr (w < 48) {
           constexpr int p = w / 12, u = w % 12, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p, e0 = 2 * p;
-          if constexpr (u == 0) hv[0] = relu1(acc2[t][r0]);
-          if constexpr (u == 1) hv[1] = relu1(acc2[t][r0 + 1]);
-          if constexpr (u == 2) mk[0] = 0u - __float_as_uint(hv[0]);
-          if constexpr (u == 3) mk[1] = 0u - __float_as_uint(hv[1]);
-          if constexpr (u == 4) mk[0] = (unsigned)((int)mk[0] >> 31);
-          if constexpr (u == 5) mk[1] = (unsigned)((int)mk[1] >> 31);
-          if constexpr (u == 6) lgs[0] = fmaf(w3f[e0 >> 2][e0 & 3], hv[0], lgs[0]);
-          if constexpr (u == 7) lgs[1] = fmaf(w3f[(e0 + 1) >> 2][(e0 + 1) & 3], hv[1], lgs[1]);
-          if constexpr (u == 8) mk[0] = __builtin_amdgcn_perm(mk[1], mk[0], 0x07060302);
-          if constexpr (u == 9) out[0][p] = w3c[0][p] & mk[0];
-          if constexpr (u == 10) out[1][p] = w3c[1][p] & mk[0];
-          if constexpr (u == 11) out[2][p] = w3c[2][p] & mk[0];
+          if constexpr (u == 0) hv[T][0] = relu1(acc2[t][T][r0]);
+          if constexpr (u == 1) hv[T][1] = relu1(acc2[t][T][r0 + 1]);
+          if constexpr (u == 2) mk[T][0] = 0u - __float_as_uint(hv[T][0]);
+          if constexpr (u == 3) mk[T][1] = 0u - __float_as_uint(hv[T][1]);
+          if constexpr (u == 4) mk[T][0] = (unsigned)((int)mk[T][0] >> 31);
+          if constexpr (u == 5) mk[T][1] = (unsigned)((int)mk[T][1] >> 31);
+          if constexpr (u == 6) lgs[T][0] = fmaf(w3f[e0 >> 2][e0 & 3], hv[T][0], lgs[T][0]);
+          if constexpr (u == 7) lgs[T][1] = fmaf(w3f[(e0 + 1) >> 2][(e0 + 1) & 3], hv[T][1], lgs[T][1]);
+          if constexpr (u == 8) mk[T][0] = __builtin_amdgcn_perm(mk[T][1], mk[T][0], 0x07060302);
+          if constexpr (u == 9) out[T][0][p] = w3c[0][p] & mk[T][0];
+          if constexpr (u == 10) out[T][1][p] = w3c[1][p] & mk[T][0];
+          if constexpr (u == 11) out[T][2][p] = w3c[2][p] & mk[T][0];
         }
       };
       dh2_load(0);
-      sfor<0, 48>([&](auto w) { dh2_item(ic<0>{}, w, bb[0]); });
+      sfor<0, 48 * NT>([&](auto w) { dh2_item(ic<0>{}, w, bb[0]); });
       sfor<0, HK>([&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
         constexpr int Z = kb == 6;
@@ -644,39 +739,48 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           else if constexpr (kb + 1 < HK) fetch(kb + 1, 0, kb + 1 == 6, 0);
           fl[(mt + 3) & 3] = lo_frag(C::S_L2T + 4 * kb + mt + 3);
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * mt, kb == 0>(accd[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+          stepN<NT, 6 * NT * mt, kb == 0>(accd[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, 2>([&](auto i) { dh2_item(ic<kb + 1>{}, ic<2 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
         });
       });
     }
-    float logit = lgs[0] + lgs[1] + (g == 1 ? skipv : 0.0f);
-    logit += __shfl_xor(logit, 32);
+    float logit[NT];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      logit[T] = lgs[T][0] + lgs[T][1] + (g == 1 ? skipv[T] : 0.0f);
+      logit[T] += __shfl_xor(logit[T], 32);
+    }
     X32_TICK(3)   // L2^T
 
     // ================================================================ dh1 = accd * [a1 > 0], dh1[skip row] = 1; three levels
-    u32x4 dhl[HK][3];
-    sfor<0, HK>([&](auto kbc) {
-      constexpr int kb = decltype(kbc)::value, t = kb >> 1;
-      constexpr int nbits = (kb >> 2) == 0 ? 32 : 8 * (HK - 4);   // pushes into this mask word
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        float v[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = 2 * p + h, k = 8 * (kb & 3) + e;
-          const unsigned bit = (unsigned)__builtin_amdgcn_sbfe((int)m1w[kb >> 2], nbits - 1 - k, 1);   // 0 or all ones
-          v[h] = __uint_as_float(__float_as_uint(accd[t][8 * (kb & 1) + e]) & bit);
-          if (kb == 6 && e == 0) v[h] = g == 1 ? 1.0f : v[h];   // position 100: d logit / d skip
-        }
-        split_pair(v[0], v[1], dhl[kb], p);
+    // Block 0 here; blocks 1..6 behind the steps of L1^T's first output tile (each step kb prepares block kb + 1).
+    u32x4 dhl[HK][NT][3];
+    float dv[NT][2];
+    SplitState dss[NT];
+    // one pair of block kb: mask bits, masked values, (the skip row's constant), split: 16 instructions per tile
+    auto dh1_item = [&](auto kbc, auto wc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kbc)::value, T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
+      if constexpr (w < 64) {
+        constexpr int p = w / 16, u = w % 16, t = kb >> 1, e0 = 2 * p;
+        constexpr int nbits = (kb >> 2) == 0 ? 32 : 8 * (HK - 4);   // pushes into this mask word
+        constexpr int k0 = 8 * (kb & 3) + e0;
+        if constexpr (u == 0) dv[T][0] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)m1w[T][kb >> 2], nbits - 1 - k0, 1));
+        if constexpr (u == 1) dv[T][1] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)m1w[T][kb >> 2], nbits - 2 - k0, 1));
+        if constexpr (u == 2) dv[T][0] = __uint_as_float(__float_as_uint(accd[t][T][8 * (kb & 1) + e0]) & __float_as_uint(dv[T][0]));
+        if constexpr (u == 3) dv[T][1] = __uint_as_float(__float_as_uint(accd[t][T][8 * (kb & 1) + e0 + 1]) & __float_as_uint(dv[T][1]));
+        if constexpr (u == 4 && kb == 6 && p == 0) dv[T][0] = g == 1 ? 1.0f : dv[T][0];   // position 100: d logit / d skip
+        if constexpr (u >= 5) split_item<u - 5>(dss[T], dv[T][0], dv[T][1], dhl[kb][T], p);
       }
-    });
+    };
+    sfor<0, 64 * NT>([&](auto w) { dh1_item(ic<0>{}, w); });
 
     X32_TICK(4)   // dh1
     // ================================================================ L1^T: din = W1ext^T dh1, then the chain rule
-    float gxs[2] = {0.f, 0.f}, gys[2] = {0.f, 0.f}, gt = 0.f;
+    float gxs[NT][2], gys[NT][2], gt[NT];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) { gxs[T][0] = gxs[T][1] = gys[T][0] = gys[T][1] = 0.f; gt[T] = 0.f; }
     int t1[2][2];
     bases_tr(std::true_type{}, t1);
     int t1m[2][2] = {{t1[0][0] + O_W1M, t1[0][1] + O_W1M}, {t1[1][0] + O_W1M, t1[1][1] + O_W1M}};
@@ -684,32 +788,34 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
     {
       u32x4 fl7[7];   // third level: ring of 7 = the steps of one output tile (three steps ahead)
       fl7[0] = fl[0]; fl7[1] = fl[1]; fl7[2] = fl[2];
-      f32x16 accp, accc;
+      f32x16 accp[NT], accc[NT];
       u32x4 fhn, fmn;   // hi / mid fragments of the next tile's first step
       f32x4 tw[2][2];
-      EvalState es[2];
-      float de[2];
+      EvalState es[NT][2];
+      float de[NT][2];
       int ep_ft = 0;
       auto ep_load = [&](int pr) __attribute__((always_inline)) {   // pair pr = registers 2 pr, 2 pr + 1
         const int off = ep_ft + 128 * ((2 * pr) >> 2) + 16 * ((2 * pr) & 3);
         tw[pr & 1][0] = lds128f(lds, off);
         tw[pr & 1][1] = lds128f(lds, off + 16);
       };
-      // chain-rule epilogue of the previous tile (plain positional features), 8 pairs x 22 instructions, 5 per slot
+      // chain-rule epilogue of the previous tile (plain positional features): per point tile 8 pairs x 22 instructions, 5 per
+      // slot, the point tiles' items alternating (the table entries are shared)
       auto ep_item = [&](auto wc) __attribute__((always_inline)) {
-        constexpr int w = decltype(wc)::value;
+        constexpr int T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
         if constexpr (w < 176) {
           constexpr int pr = w / 22, u = w % 22, which = u & 1, st = u >> 1, r = 2 * pr + which;
-          if constexpr (u == 0 && pr < 7) ep_load(pr + 1);
-          if constexpr (st < 8) eval_item<st>(es[which], tw[pr & 1][which], ux, uy);
-          if constexpr (st == 8) de[which] = accp[r] * es[which].v;
-          if constexpr (st == 9) gxs[which] = fmaf(de[which], tw[pr & 1][which].x, gxs[which]);
-          if constexpr (st == 10) gys[which] = fmaf(de[which], tw[pr & 1][which].y, gys[which]);
+          if constexpr (u == 0 && pr < 7 && T == 0) ep_load(pr + 1);
+          if constexpr (st < 8) eval_item<st>(es[T][which], tw[pr & 1][which], ux[T], uy[T]);
+          if constexpr (st == 8) de[T][which] = accp[T][r] * es[T][which].v;
+          if constexpr (st == 9) gxs[T][which] = fmaf(de[T][which], tw[pr & 1][which].x, gxs[T][which]);
+          if constexpr (st == 10) gys[T][which] = fmaf(de[T][which], tw[pr & 1][which].y, gys[T][which]);
         }
       };
-      auto l1t_tile = [&](auto hook_c, int mt, f32x16& acc) __attribute__((always_inline)) {
-        constexpr bool HOOK = decltype(hook_c)::value;
-        if constexpr (HOOK) { ep_ft = ftdl + 512 * (mt - 1); ep_load(0); }
+      // HOOK 1: the epilogue of tile mt - 1 behind this tile's steps;  2 (tile 0): dh1 block kb + 1 behind step kb
+      auto l1t_tile = [&](auto hook_c, int mt, f32x16 (&acc)[NT]) __attribute__((always_inline)) {
+        constexpr int HOOK = decltype(hook_c)::value;
+        if constexpr (HOOK == 1) { ep_ft = ftdl + 512 * (mt - 1); ep_load(0); }
         auto fetch = [&](int kbn, int mtn, int zn, u32x4& oh, u32x4& om) __attribute__((always_inline)) {
           const int off = 64 * mtn + (zn ? 0 : 16 * RS1 * kbn);
           oh = lds_tr(lds, O_W1H + t1[0][zn] + off, O_W1H + t1[1][zn] + off);
@@ -725,45 +831,53 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
             fl7[(kb + 3) % 7] = lo_frag(st >= C::STEPS ? st - C::STEPS : st);
           }
           __builtin_amdgcn_sched_barrier(0);
-          step6<6 * kb, kb == 0>(acc, fh[kb & 1], fm[kb & 1], fl7[kb], dhl[kb], [&](auto slot) {
-            if constexpr (HOOK) sfor<0, 5>([&](auto i) { ep_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}); });
+          stepN<NT, 6 * NT * kb, kb == 0>(acc, fh[kb & 1], fm[kb & 1], fl7[kb], dhl[kb], [&](auto slot) {
+            if constexpr (HOOK == 1) sfor<0, 5>([&](auto i) { ep_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}); });
+            if constexpr (HOOK == 2 && kb + 1 < HK)
+              sfor<0, 11>([&](auto i) { dh1_item(ic<kb + 1>{}, ic<11 * (decltype(slot)::value - 6 * NT * kb) + decltype(i)::value>{}); });
           });
         });
       };
       // epilogue of a tile that can hold angle / ones / pad positions: evaluated after its steps
-      auto ep_any = [&](int mt, const f32x16& acc) __attribute__((always_inline)) {
+      auto ep_any = [&](int mt, const f32x16 (&acc)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int off = 512 * mt + 128 * (r >> 2) + 16 * (r & 3);
-          const f32x4 e = lds128f(lds, ftdl + off);
-          const float isa = *reinterpret_cast<const float*>(lds + isl + (off >> 2));
-          float arg = fmaf(e.x, ux, fmaf(e.y, uy, e.z));
-          const float za = (th + e.z) * e.x;
-          arg = isa != 0.0f ? za : arg;
-          const float d = acc[r] * sin_halfturns_hw(arg, e.w);
-          gxs[r & 1] = fmaf(d, isa != 0.0f ? 0.0f : e.x, gxs[r & 1]);
-          gys[r & 1] = fmaf(d, e.y, gys[r & 1]);
-          gt = fmaf(d, isa != 0.0f ? e.x : 0.0f, gt);
-        }
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int off = 512 * mt + 128 * (r >> 2) + 16 * (r & 3);
+            const f32x4 e = lds128f(lds, ftdl + off);
+            const float isa = *reinterpret_cast<const float*>(lds + isl + (off >> 2));
+            float arg = fmaf(e.x, ux[T], fmaf(e.y, uy[T], e.z));
+            const float za = (th[T] + e.z) * e.x;
+            arg = isa != 0.0f ? za : arg;
+            const float d = acc[T][r] * sin_halfturns_hw(arg, e.w);
+            gxs[T][r & 1] = fmaf(d, isa != 0.0f ? 0.0f : e.x, gxs[T][r & 1]);
+            gys[T][r & 1] = fmaf(d, e.y, gys[T][r & 1]);
+            gt[T] = fmaf(d, isa != 0.0f ? e.x : 0.0f, gt[T]);
+          }
       };
       {
         fhn = lds_tr(lds, O_W1H + t1[0][0], O_W1H + t1[1][0]);
         fmn = lds_tr(lds, t1m[0][0], t1m[1][0]);
       }
-      l1t_tile(std::false_type{}, 0, accp);
+      l1t_tile(ic<2>{}, 0, accp);
 #pragma unroll 1
       for (int mt = 1; mt < C::NMT; ++mt) {
-        l1t_tile(std::true_type{}, mt, accc);
-        accp = accc;
+        l1t_tile(ic<1>{}, mt, accc);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) accp[T] = accc[T];
       }
       X32_TICK(5)   // L1^T steps + hooked epilogues
       ep_any(C::NMT - 1, accp);
       fl[0] = fl7[0]; fl[1] = fl7[1]; fl[2] = fl7[2];   // steps 0..2 of the next chunk (fetched during the last tile)
     }
-    float gx = gxs[0] + gxs[1], gy = gys[0] + gys[1];
-    gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gt += __shfl_xor(gt, 32);
-    if (a.out4 && g == 0 && pidx < a.n_points)
-      *reinterpret_cast<f32x4*>(a.out4 + pidx * 4) = f32x4{logit, gx / geo.sigma, gy / geo.sigma, gt};
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      float gx = gxs[T][0] + gxs[T][1], gy = gys[T][0] + gys[T][1], gth = gt[T];
+      gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gth += __shfl_xor(gth, 32);
+      if (a.out4 && g == 0 && pidx[T] < a.n_points)
+        *reinterpret_cast<f32x4*>(a.out4 + pidx[T] * 4) = f32x4{logit[T], gx / geo.sigma, gy / geo.sigma, gth};
+    }
     X32_TICK(6)   // last epilogue + output
   }
 #ifdef X32_PHASE_PROFILE
@@ -815,12 +929,12 @@ static int buffers_for_stream(size_t bytes, hipStream_t stream, void** out, Slot
   return NFOPP_OK;
 }
 
-template <int NKB, int MODE, int XT>
+template <int NKB, int MODE, int XT, int NT>
 static int launch_shape(const OnfKernelArgs& a, hipStream_t stream) {
   using C = Cfg<NKB>;
-  constexpr int CH = (XT / 64) * 32;
+  constexpr int CH = (XT / 64) * 32 * NT;
   static bool attr_set[MAX_DEVICES] = {};
-  auto kern = onf_x32_kernel<NKB, MODE, XT>;
+  auto kern = onf_x32_kernel<NKB, MODE, XT, NT>;
   int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), IMG_BYTES, attr_set);
   if (rc != NFOPP_OK) return rc;
   void* buf = nullptr;
@@ -876,10 +990,14 @@ static int launch_shape(const OnfKernelArgs& a, hipStream_t stream) {
 
 template <int NKB, int MODE>
 static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
-#ifdef X32_THREADS   /* development A/B: one shape at every size */
-  return launch_shape<NKB, MODE, X32_THREADS>(a, stream);
+#ifdef X32_THREADS   /* development A/B: one shape at every size (X32_TILES = 32-sample tiles per wave) */
+#ifndef X32_TILES
+#define X32_TILES 1
+#endif
+  return launch_shape<NKB, MODE, X32_THREADS, X32_TILES>(a, stream);
 #else
-  return a.n_points < (long long)query_cus() * 256 ? launch_shape<NKB, MODE, 256>(a, stream) : launch_shape<NKB, MODE, 512>(a, stream);
+  return a.n_points < (long long)query_cus() * 256 ? launch_shape<NKB, MODE, 256, 1>(a, stream)
+                                                   : launch_shape<NKB, MODE, 512, 1>(a, stream);
 #endif
 }
 
