@@ -259,7 +259,7 @@ def roofline(matrix_path, achieved, k1_ms, samples, traffic, traffic_source):
     if matrix_path in ("split", "split16"):
         peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
         x32 = matrix_path == "split"
-        out.update({"peak": peak, "frac": achieved / peak, "kernel": "onf_x32_kernel<14,0>" if x32 else "onf_split_kernel<14,2,0>",
+        out.update({"peak": peak, "frac": achieved / peak, "kernel": "onf_x32_kernel<14,0,512,1>" if x32 else "onf_split_kernel<14,2,0>",
                     "pipe": "bf16 MFMA %s, %d partial products per fp32 multiply (exact 3-level operand split)"
                             % ("32x32x16" if x32 else "16x16x32", SPLIT_PRODUCTS),
                     "pipe_peak": PEAK_BF16_MFMA_TFLOPS, "executed_tflops": achieved * SPLIT_PRODUCTS,
