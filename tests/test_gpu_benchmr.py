@@ -300,7 +300,7 @@ def test_fit_gradient_repeats_bit_for_bit():
     times on the same inputs, must come out bit for bit the same.  This test found a hazard hipcc does not pad (a packed fma
     with op_sel reading a register pair an LDS load had just filled: csrc/onf_wgrad.hip) -- one process in ten
     saw single repeats differ in the 7th digit of dW1.  On failure it says which parameter blocks moved and whether pass 1's
-    stored factors did; tools/repro_loop.sh runs the file N times to measure a failure rate."""
+    stored factors did."""
     z = load_golden("traj_benchmr_n512.npz")
     onf, cfg = gc.make_onf(z["cfg"], z["params"])
     P = 4096 * 621
