@@ -303,6 +303,13 @@ __device__ __forceinline__ void eval_item(EvalState& s, const f32x4& tw, float u
 #define X32_TICK(SLOT)
 #endif
 
+// Third-level (blob) fragments are fetched LOOK steps ahead into a ring of RL registers sets
+#ifndef X32_LOOK
+#define X32_LOOK 3   /* development A/B: 6 = a ring of 8 */
+#endif
+constexpr int LOOK = X32_LOOK, RL = LOOK <= 3 ? 4 : 8;
+static_assert(LOOK == 3 || LOOK == 6, "look-ahead of the third-level fragments");
+
 // One MFMA step for NT point tiles that share the weight fragments: the six partial products in the order of step6, each
 // issued for tile 0 .. NT-1 in turn (independent accumulators alternate on the matrix pipe); WORK(slot) runs behind MFMA
 // number slot - SLOT0 (6 NT slots per step).
@@ -434,8 +441,9 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
   if (n_chunks <= (long long)blockIdx.x) return;   // (an empty live list: nothing to do)
   // third-level fragments: ring of 4, three steps ahead, running on across the GEMMs (blob steps are consecutive) and,
   // at the end of a chunk, on into the first steps of the next
-  u32x4 fl[4];
-  fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
+  u32x4 fl[RL];
+#pragma unroll
+  for (int q = 0; q < LOOK; ++q) fl[q] = lo_frag(q);
   // Samples.  Both lane halves of a wave need each tile's 32 poses, so forming them in all 64 lanes would do every draw,
   // interpolation and normalisation twice.  Each pose is formed by exactly ONE lane (the arithmetic of load_point: same
   // bits) and the halves exchange (5 cross-half moves).  NT = 2: the lower half forms tile 0's poses, the upper half tile
@@ -583,9 +591,9 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
             const int off = 64 * ((kb + 1) >> 1);
             fh[0] = lds128(lds, O_W1H + w1f[PAR ^ 1][0] + off); fm[0] = lds128(lds, w1m[PAR ^ 1][0] + off);
           }
-          fl[(mt + 3) & 3] = lo_frag(C::S_L1 + 4 * kb + mt + 3);
+          fl[(4 * PAR + mt + LOOK) & (RL - 1)] = lo_frag(C::S_L1 + 4 * kb + mt + LOOK);
           __builtin_amdgcn_sched_barrier(0);
-          stepN<NT, 6 * NT * mt, FIRST>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[mt], bc, [&](auto slot) {
+          stepN<NT, 6 * NT * mt, FIRST>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[(4 * PAR + mt) & (RL - 1)], bc, [&](auto slot) {
             if constexpr (HOOK == 1) sfor<0, 5>([&](auto i) { l1_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}, bn); });
             if constexpr (HOOK == 2) sfor<0, 6>([&](auto i) { l1_item_any(ic<6 * decltype(slot)::value + decltype(i)::value>{}, bn); });
           });
@@ -654,9 +662,9 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
             const int ad = w2f[0] ^ ((kb + 1) << 5);
             fh[0] = lds128(lds, O_W2H + ad); fm[0] = lds128(lds, O_W2M + ad);
           }
-          fl[(mt + 3) & 3] = lo_frag(C::S_L2 + 4 * kb + mt + 3);
+          fl[(C::S_L2 + 4 * kb + mt + LOOK) & (RL - 1)] = lo_frag(C::S_L2 + 4 * kb + mt + LOOK);
           __builtin_amdgcn_sched_barrier(0);
-          stepN<NT, 6 * NT * mt, kb == 0>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+          stepN<NT, 6 * NT * mt, kb == 0>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[(C::S_L2 + 4 * kb + mt) & (RL - 1)], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, 3>([&](auto i) { h1_item(ic<kb + 1>{}, ic<3 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
@@ -680,7 +688,8 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
         lg += __shfl_xor(lg, 32);
         if (g == 0 && pidx[T] < a.n_points) *reinterpret_cast<f32x4*>(a.out4 + pidx[T] * 4) = f32x4{lg, 0.f, 0.f, 0.f};
       }
-      fl[0] = lo_frag(0); fl[1] = lo_frag(1); fl[2] = lo_frag(2);
+#pragma unroll
+      for (int q = 0; q < LOOK; ++q) fl[q] = lo_frag(q);
       continue;
     }
 
@@ -737,9 +746,9 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           if constexpr (mt == 0 && kb == 0) fetch(0, 0, 0, 0);
           if constexpr (mt < 3) fetch(kb, mt + 1, Z, (mt + 1) & 1);
           else if constexpr (kb + 1 < HK) fetch(kb + 1, 0, kb + 1 == 6, 0);
-          fl[(mt + 3) & 3] = lo_frag(C::S_L2T + 4 * kb + mt + 3);
+          fl[(C::S_L2T + 4 * kb + mt + LOOK) & (RL - 1)] = lo_frag(C::S_L2T + 4 * kb + mt + LOOK);
           __builtin_amdgcn_sched_barrier(0);
-          stepN<NT, 6 * NT * mt, kb == 0>(accd[mt], fh[mt & 1], fm[mt & 1], fl[mt], bb[kb & 1], [&](auto slot) {
+          stepN<NT, 6 * NT * mt, kb == 0>(accd[mt], fh[mt & 1], fm[mt & 1], fl[(C::S_L2T + 4 * kb + mt) & (RL - 1)], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, 2>([&](auto i) { dh2_item(ic<kb + 1>{}, ic<2 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
@@ -786,8 +795,9 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
     int t1m[2][2] = {{t1[0][0] + O_W1M, t1[0][1] + O_W1M}, {t1[1][0] + O_W1M, t1[1][1] + O_W1M}};
     X32_OPAQUE2(t1m);
     {
-      u32x4 fl7[7];   // third level: ring of 7 = the steps of one output tile (three steps ahead)
-      fl7[0] = fl[0]; fl7[1] = fl[1]; fl7[2] = fl[2];
+      u32x4 fl7[7];   // third level: ring of 7 = the steps of one output tile (LOOK steps ahead)
+#pragma unroll
+      for (int q = 0; q < LOOK; ++q) fl7[q] = fl[(C::S_L1T + q) & (RL - 1)];
       f32x16 accp[NT], accc[NT];
       u32x4 fhn, fmn;   // hi / mid fragments of the next tile's first step
       f32x4 tw[2][2];
@@ -827,8 +837,8 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           if constexpr (kb + 1 < HK) fetch(kb + 1, mt, kb + 1 == 6, fh[(kb + 1) & 1], fm[(kb + 1) & 1]);
           else fetch(0, mt + 1, 0, fhn, fmn);   // past the last tile: a harmless in-image read
           {   // past the last step of the chunk: the next chunk's first steps
-            const int st = C::S_L1T + HK * mt + kb + 3;
-            fl7[(kb + 3) % 7] = lo_frag(st >= C::STEPS ? st - C::STEPS : st);
+            const int st = C::S_L1T + HK * mt + kb + LOOK;
+            fl7[(kb + LOOK) % 7] = lo_frag(st >= C::STEPS ? st - C::STEPS : st);
           }
           __builtin_amdgcn_sched_barrier(0);
           stepN<NT, 6 * NT * kb, kb == 0>(acc, fh[kb & 1], fm[kb & 1], fl7[kb], dhl[kb], [&](auto slot) {
@@ -869,7 +879,8 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       }
       X32_TICK(5)   // L1^T steps + hooked epilogues
       ep_any(C::NMT - 1, accp);
-      fl[0] = fl7[0]; fl[1] = fl7[1]; fl[2] = fl7[2];   // steps 0..2 of the next chunk (fetched during the last tile)
+#pragma unroll
+      for (int q = 0; q < LOOK; ++q) fl[q] = fl7[q];   // the first steps of the next chunk (fetched during the last tile)
     }
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
