@@ -45,7 +45,10 @@ int launch_onf_split_train_kernel(const OnfKernelArgs& a, hipStream_t stream, in
 bool onf_split_enabled();
 // csrc/onf_x32.hip: the bf16x3 split path on 32x32x16 tiles (mode 0 / 2), one 32-sample tile per wave
 bool onf_x32_supports(const OnfGeom& g);
+bool onf_use_x32(const OnfGeom& g);   // matrix path 1 and a feature dimension the 32x32x16 kernel covers
 int launch_onf_x32_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only);
+// training pass of csrc/onf_x32.hip: factors in x32 order (csrc/onf_wgrad.hip: WgradArgs::x32_order), loss partials [grid * 8]
+int launch_onf_x32_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);
 int launch_onf_logits_kernel(const OnfKernelArgs& a, hipStream_t stream);
 int launch_onf_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out);
 int onf_train_grid_upper_bound();

@@ -82,6 +82,10 @@ struct WgradArgs {
   OnfGeom geom;
   const float* params;
   int aug_feature;
+  // 0: pass 1 was onf_fused.hip / onf_split.hip (factors in their slot orders, layouts P and Q);  1: pass 1 was onf_x32.hip:
+  // a factor's slot IS the feature / hidden-unit index, ones feature = geom.fin, h1's ones unit = 101, rho row of dh1 = 100,
+  // and dh2 is rebuilt WITHOUT W3a (G2 = sum_p rho_p [a2_p > 0] h1_p^T; the gather kernel applies W3a)
+  int x32_order;
   // stored factors, back to back in this order (carve_wgrad):  h1 [P,112] | dh1 [P,112] | de [P,WIN] | record [P,12]
   const float* ws;
   long long P;
@@ -473,7 +477,8 @@ __device__ __forceinline__ void mfma_split_pair(const s16x8 (&a)[3], const s16x8
   c0 = mfma_bf16(a[0], b0[1], c0); c1 = mfma_bf16(a[0], b1[1], c1);
   c0 = mfma_bf16(a[0], b0[0], c0); c1 = mfma_bf16(a[0], b1[0], c1);
 }
-template <int NKT>
+// XO: the factors are in x32 order (WgradArgs::x32_order, a.x32_order == XO)
+template <int NKT, bool XO>
 __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const WgradArgs a) {
   using L = WsLayout<NKT>;
   constexpr int WIN = L::WIN, H4 = HS / 4, W4 = WIN / 4;
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     for (int k = tid; k < L::L_TOTAL; k += WG_THREADS) lds[k] = 0.0f;   // also: u-tile columns 4..15, image pad columns
     __syncthreads();
     for (int f = tid; f < 32 * ((NKT + 1) / 2); f += WG_THREADS) {
-      const int slot = slot_layout_p(f);
+      const int slot = XO ? f : slot_layout_p(f);
       if (slot >= WIN) continue;
       float wx = 0.f, wy = 0.f, b = 0.f, fr = 0.f, qh = 0.f, isa = 0.f;
       if (f < g.n_enc) {
@@ -508,7 +513,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       float* e = lds + L::L_FT + slot;
       e[0] = wx; e[WIN] = wy; e[2 * WIN] = b; e[3 * WIN] = fr; e[4 * WIN] = qh; e[5 * WIN] = isa;
     }
-    for (int h = tid; h < NFOPP_HIDDEN; h += WG_THREADS) lds[L::L_W3A + hidden_slot(h, false)] = P[g.off_w3 + h];
+    // factor of the rebuilt dh2: W3a in slot order, or 1 (x32 order: rho * [a2 > 0] alone, see WgradArgs)
+    for (int h = tid; h < NFOPP_HIDDEN; h += WG_THREADS) lds[L::L_W3A + (XO ? h : hidden_slot(h, false))] = XO ? 1.0f : P[g.off_w3 + h];
   }
   __syncthreads();   // the tables are read into registers below
 
@@ -551,7 +557,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     // HBM loads as raw buffer loads: one resource per array and chunk (base = the chunk's first row, size = the rows that
     // exist), so the per-item offset q * row + 16 c is a 32-bit chunk-invariant and rows past P read as zeros without a branch
     auto chunk_rsrc = [&](const float* base, long long chunk, int row_floats) __attribute__((always_inline)) {
+#ifdef NFOPP_WG_REVERSE   /* development A/B: walk the samples from the end (what pass 1 wrote last is still in the caches) */
+      const long long p0 = chunk < n_chunks ? (n_chunks - 1 - chunk) * KS : a.P;
+#else
       const long long p0 = chunk * KS;
+#endif
       long long rows = a.P - p0;
       rows = rows > KS ? KS : (rows < 0 ? 0 : rows);
       const float* ptr = base + (rows > 0 ? p0 : 0) * row_floats;
@@ -579,7 +589,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       const auto rsrc = chunk_rsrc(ws_rec, chunk, 12);
       st = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rq * 48 + 16 * rc, 0, 0));
     };
-    auto commit_rec = [&](const f32x4& st, int parity) __attribute__((always_inline)) {
+    // XO: dh2 = rho * [a2 > 0] takes only the values rho and 0, so rho is split ONCE per sample, here: the record's unused
+    // words 5..7 carry its three levels, each in both halves of the word, and a dh2 pair is a level word ANDed with a mask
+    auto commit_rec = [&](f32x4 st, int parity) __attribute__((always_inline)) {
+      if (XO && rc == 1) {
+        float r = st.x;
+        const unsigned h = __float_as_uint(r) & 0xffff0000u;
+        r -= __uint_as_float(h);
+        const unsigned m = __float_as_uint(r) & 0xffff0000u;
+        r -= __uint_as_float(m);
+        const unsigned l = __float_as_uint(r) & 0xffff0000u;   // exact: the third level's low half-word is zero
+        st.y = __uint_as_float(h | (h >> 16)); st.z = __uint_as_float(m | (m >> 16)); st.w = __uint_as_float(l | (l >> 16));
+      }
       *reinterpret_cast<f32x4*>(lds + L::REC + parity * KS * 12 + rq * 12 + 4 * rc) = st;
     };
     auto commit_h = [&](int img, const f32x4 (&st)[N_H]) __attribute__((always_inline)) {
@@ -634,6 +655,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       for (int j = 0; j < N_H; ++j) {   // dh2 slots 4c .. 4c+3 = rho * W3a * [a2 > 0]: tile c >> 2, lane group c & 3
         int q, c;
         unpack(hqc[j], q, c);
+        if constexpr (XO) {   // (W3a is applied by the gather kernel)
+          const f32x4 lv = *reinterpret_cast<const f32x4*>(rec + q * 12 + 4);   // rho | its levels, doubled
+          const int word = (int)__float_as_uint(rec[q * 12 + 8 + (c & 3)]), sh = 4 * (c >> 2);
+          const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(word, sh, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 1, 1);
+          const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 3, 1);
+          const unsigned k01 = __builtin_amdgcn_perm(m1, m0, 0x07060302), k23 = __builtin_amdgcn_perm(m3, m2, 0x07060302);
+          const int at = q * L::R_H + 2 * c;
+          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + at) = u32x2{__float_as_uint(lv.y) & k01, __float_as_uint(lv.y) & k23};
+          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + L::P_H + at) = u32x2{__float_as_uint(lv.z) & k01, __float_as_uint(lv.z) & k23};
+          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + 2 * L::P_H + at) = u32x2{__float_as_uint(lv.w) & k01, __float_as_uint(lv.w) & k23};
+          continue;
+        }
         const unsigned bits = __float_as_uint(rec[q * 12 + 8 + (c & 3)]) >> (4 * (c >> 2));
         const float rho = rec[q * 12 + 4];
         f32x4 v;
@@ -819,6 +852,7 @@ __global__ __launch_bounds__(256) void onf_wgrad_reduce_kernel(const float* part
 struct GatherArgs {
   OnfGeom geom;
   int nkt, aug_in_slot;
+  int x32_order;              // WgradArgs::x32_order
   const float* params;
   const float* reduced;       // [NTILES][256]
   const float* g4;            // [112] dW3[:100] in h2 slot order (reduced per-wave partials of pass 1)
@@ -836,45 +870,55 @@ __global__ __launch_bounds__(256) void onf_wgrad_gather_kernel(const GatherArgs 
   const int NKT = a.nkt;
   const int o = blockIdx.x * 256 + threadIdx.x;
   const int T_G2 = 7 * NKT, T_G3 = 7 * NKT + 49;
+  const bool xo = a.x32_order != 0;
+  // slot of an input feature / of a hidden unit as a row or column of h1, dh1 (layout Q) / of h2, dh2 (layout P)
+  auto in_slot = [&](int f) { return xo ? f : slot_layout_p(f); };
+  auto h1_slot = [&](int h) { return xo ? h : hidden_slot(h, true); };
+  auto h2_slot = [&](int h) { return xo ? h : hidden_slot(h, false); };
+  const int ones_h1 = xo ? 101 : AUG_HIDDEN_SLOT, rho_row = xo ? 100 : AUG_HIDDEN_SLOT;
+  auto g1 = [&](int rs, int cs) { return tile_elem(a.reduced, (rs / 16) * NKT + cs / 16, rs % 16, cs % 16); };
+  auto g2 = [&](int rs, int cs) { return tile_elem(a.reduced, T_G2 + (rs / 16) * 7 + cs / 16, rs % 16, cs % 16); };
+  auto g3 = [&](int s, int c) { return tile_elem(a.reduced, T_G3 + s / 16, s % 16, c); };
   if (o < g.n_params) {
     float v = 0.f;
     if (g.n_ang && o < g.off_ang_b + g.n_ang) {            // d/d angle bias = f_k * sum dz_k
-      const int k = o - g.off_ang_b, s = slot_layout_p(g.n_enc + k);
-      v = a.params[g.off_ang_f + k] * tile_elem(a.reduced, T_G3 + s / 16, s % 16, 2);
+      const int k = o - g.off_ang_b;
+      v = a.params[g.off_ang_f + k] * g3(in_slot(g.n_enc + k), 2);
     } else if (g.n_ang && o < g.off_ang_f + g.n_ang) {     // d/d frequency = sum dz_k (theta + b_k)
-      const int k = o - g.off_ang_f, s = slot_layout_p(g.n_enc + k);
-      v = tile_elem(a.reduced, T_G3 + s / 16, s % 16, 3) +
-          a.params[g.off_ang_b + k] * tile_elem(a.reduced, T_G3 + s / 16, s % 16, 2);
+      const int k = o - g.off_ang_f, s = in_slot(g.n_enc + k);
+      v = g3(s, 3) + a.params[g.off_ang_b + k] * g3(s, 2);
     } else if (o < g.off_b1) {                             // W1[m][k]
       const int q = o - g.off_w1, m = q / g.fin, k = q - m * g.fin;
-      const int rs = hidden_slot(m, true), cs = slot_layout_p(k);
-      v = tile_elem(a.reduced, (rs / 16) * NKT + cs / 16, rs % 16, cs % 16);
+      v = g1(h1_slot(m), in_slot(k));
     } else if (o < g.off_w2) {                             // b1[m]
-      const int rs = hidden_slot(o - g.off_b1, true), cs = a.aug_in_slot;
-      v = tile_elem(a.reduced, (rs / 16) * NKT + cs / 16, rs % 16, cs % 16);
+      v = g1(h1_slot(o - g.off_b1), a.aug_in_slot);
     } else if (o < g.off_b2) {                             // W2[m][k]
       const int q = o - g.off_w2, m = q / NFOPP_HIDDEN, k = q - m * NFOPP_HIDDEN;
-      const int rs = hidden_slot(m, false), cs = hidden_slot(k, true);
-      v = tile_elem(a.reduced, T_G2 + (rs / 16) * 7 + cs / 16, rs % 16, cs % 16);
+      v = g2(h2_slot(m), h1_slot(k));
+      if (xo) v *= a.params[g.off_w3 + m];
     } else if (o < g.off_w3) {                             // b2[m]
-      const int rs = hidden_slot(o - g.off_b2, false), cs = AUG_HIDDEN_SLOT;
-      v = tile_elem(a.reduced, T_G2 + (rs / 16) * 7 + cs / 16, rs % 16, cs % 16);
+      const int m = o - g.off_b2;
+      v = g2(h2_slot(m), ones_h1);
+      if (xo) v *= a.params[g.off_w3 + m];
     } else if (o < g.off_b3) {                             // W3[j]
       const int j = o - g.off_w3;
-      if (j < NFOPP_HIDDEN) {
+      if (j < NFOPP_HIDDEN && !xo) {
         v = a.g4[hidden_slot(j, false)];
+      } else if (j < NFOPP_HIDDEN) {
+        // sum_p rho_p relu(a2_p)[j] = sum_p rho_p [a2_p[j] > 0] (W2[j] . h1_p + b2[j]) = W2[j] . S[j] + b2[j] S[j][ones]:
+        // h2 never has to be summed where it is formed (fixed order: k ascending, the bias last)
+        for (int k = 0; k < NFOPP_HIDDEN; ++k) v = fmaf(a.params[g.off_w2 + j * NFOPP_HIDDEN + k], g2(j, k), v);
+        v = fmaf(a.params[g.off_b2 + j], g2(j, ones_h1), v);
       } else {
-        const int cs = slot_layout_p(j - NFOPP_HIDDEN);
-        v = tile_elem(a.reduced, 6 * NKT + cs / 16, 1, cs % 16);
+        v = g1(rho_row, in_slot(j - NFOPP_HIDDEN));
       }
     } else if (o == g.off_b3) {
-      v = tile_elem(a.reduced, 6 * NKT + a.aug_in_slot / 16, 1, a.aug_in_slot % 16);
+      v = g1(rho_row, a.aug_in_slot);
     } else if (g.off_be < 0 || o < g.off_be) {             // We[f][c]
-      const int q = o - g.off_we, f = q >> 1, s = slot_layout_p(f);
-      v = tile_elem(a.reduced, T_G3 + s / 16, s % 16, q & 1);
+      const int q = o - g.off_we;
+      v = g3(in_slot(q >> 1), q & 1);
     } else {                                               // be[f]
-      const int s = slot_layout_p(o - g.off_be);
-      v = tile_elem(a.reduced, T_G3 + s / 16, s % 16, 2);
+      v = g3(in_slot(o - g.off_be), 2);
     }
     a.grad[o] = v;
   }
@@ -896,9 +940,8 @@ struct WgradWs {  // float offsets into the workspace
   int win, ntiles, grid_cap;
 };
 
-static WgradWs carve_wgrad(const OnfGeom& g, long long P) {
+static WgradWs carve_wgrad(const OnfGeom& g, long long P, int nkt) {
   WgradWs w;
-  const int nkt = (g.fin + 15) / 16;
   w.win = 16 * nkt;
   w.ntiles = 8 * nkt + 49;
   w.grid_cap = onf_train_grid_upper_bound();
@@ -917,7 +960,9 @@ static WgradWs carve_wgrad(const OnfGeom& g, long long P) {
   return w;
 }
 
-size_t wgrad_workspace_bytes(const OnfGeom& g, long long P) { return (size_t)carve_wgrad(g, P).total * sizeof(float); }
+// sized for the longer of the two row lengths (x32 order reserves a pad position for the ones feature: (fin + 16) / 16 tiles),
+// so the answer does not depend on the matrix path in force when the fit runs
+size_t wgrad_workspace_bytes(const OnfGeom& g, long long P) { return (size_t)carve_wgrad(g, P, (g.fin + 16) / 16).total * sizeof(float); }
 
 template <int NKT>
 static int launch_wgrad(const WgradArgs& a, int grid, hipStream_t st) {
@@ -931,11 +976,11 @@ static int launch_wgrad(const WgradArgs& a, int grid, hipStream_t st) {
   return NFOPP_OK;
 }
 
-template <int NKT>
-static int launch_wgrad_split(const WgradArgs& a, int grid, hipStream_t st) {
+template <int NKT, bool XO>
+static int launch_wgrad_split_o(const WgradArgs& a, int grid, hipStream_t st) {
   using L = WsLayout<NKT>;
   static bool attr_set[MAX_DEVICES] = {};
-  auto kern = onf_wgrad_split_kernel<NKT>;
+  auto kern = onf_wgrad_split_kernel<NKT, XO>;
   const int rc_attr = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L::LDS_BYTES, attr_set);
   if (rc_attr != NFOPP_OK) return rc_attr;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WG_THREADS), L::LDS_BYTES, st, a);
@@ -943,12 +988,19 @@ static int launch_wgrad_split(const WgradArgs& a, int grid, hipStream_t st) {
   return NFOPP_OK;
 }
 
+template <int NKT>
+static int launch_wgrad_split(const WgradArgs& a, int grid, hipStream_t st) {
+  return a.x32_order ? launch_wgrad_split_o<NKT, true>(a, grid, st) : launch_wgrad_split_o<NKT, false>(a, grid, st);
+}
+
 // gradient of the mean BCE loss over `count` samples (inv_count = 1 / count) into grad[n_params + 2]
 int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samples, const float* labels, long long P,
                         float inv_count, float* grad, float* ws, hipStream_t st) {
-  const WgradWs w = carve_wgrad(g, P);
-  const int nkt = (g.fin + 15) / 16;
-  const int aug = find_aug_feature(g.fin, nkt);
+  // pass 1 on the 32x32x16 kernel (matrix path 1, the feature dimensions it covers): factors in x32 order
+  const bool xo = onf_use_x32(g);
+  const int nkt = xo ? (g.fin + 16) / 16 : (g.fin + 15) / 16;
+  const WgradWs w = carve_wgrad(g, P, nkt);
+  const int aug = xo ? g.fin : find_aug_feature(g.fin, nkt);
   NFOPP_REQUIRE(aug >= 0, "no pad feature available for the ones column (fin = %d)", g.fin);
   OnfKernelArgs a = {};
   a.geom = g; a.params = params; a.points = samples; a.n_points = P; a.out4 = nullptr;
@@ -956,11 +1008,21 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
   a.ws_h1 = ws + w.h1; a.ws_dh1 = ws + w.dh1; a.ws_de = ws + w.de; a.ws_u = ws + w.rec;
   a.loss_partial = ws + w.loss; a.g4_partial = ws + w.g4_partial;
   int grid_fwd = 0;
-  int rc = launch_onf_train_kernel(a, st, &grid_fwd);
+  int rc = NFOPP_OK;
+#ifdef NFOPP_DEV_SKIP_PASS1   /* development timing: pass 2 alone on the factors of the first calls (env NFOPP_DEV_SKIP_PASS1) */
+  static int dev_calls = 0;
+  static int dev_grid = 0;
+  if (getenv("NFOPP_DEV_SKIP_PASS1") && dev_calls++ >= 2) grid_fwd = dev_grid;
+  else
+#endif
+  rc = xo ? launch_onf_x32_train_kernel(a, st, &grid_fwd) : launch_onf_train_kernel(a, st, &grid_fwd);
   if (rc) return rc;
+#ifdef NFOPP_DEV_SKIP_PASS1
+  dev_grid = grid_fwd;
+#endif
 
   WgradArgs wa;
-  wa.geom = g; wa.params = params; wa.aug_feature = aug;
+  wa.geom = g; wa.params = params; wa.aug_feature = aug; wa.x32_order = xo ? 1 : 0;
   wa.ws = ws + w.h1; wa.P = P; wa.partial = ws + w.partial;   // arrays back to back from w.h1 (see carve_wgrad)
   const bool split = onf_split_enabled();   // pass 2 follows pass 1's matrix path
   const int kc = split ? KS : KC;
@@ -981,10 +1043,13 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
   // loss and dW3[:100]: per-wave partials of pass 1
   hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.loss, ws + w.loss_sum, 1, grid_fwd * WAVES);
   NFOPP_HIP(hipGetLastError());
-  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(HS), dim3(256), 0, st, ws + w.g4_partial, ws + w.g4, HS, grid_fwd * WAVES);
-  NFOPP_HIP(hipGetLastError());
+  if (!xo) {   // (x32 order: dW3[:100] comes out of G2 in the gather kernel)
+    hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(HS), dim3(256), 0, st, ws + w.g4_partial, ws + w.g4, HS, grid_fwd * WAVES);
+    NFOPP_HIP(hipGetLastError());
+  }
   GatherArgs ga;
-  ga.geom = g; ga.nkt = nkt; ga.aug_in_slot = slot_layout_p(aug);   ga.params = params; ga.reduced = ws + w.reduced; ga.g4 = ws + w.g4; ga.loss_partial = ws + w.loss_sum; ga.grad = grad; ga.count = (float)P;
+  ga.x32_order = xo ? 1 : 0;
+  ga.geom = g; ga.nkt = nkt; ga.aug_in_slot = xo ? aug : slot_layout_p(aug);   ga.params = params; ga.reduced = ws + w.reduced; ga.g4 = ws + w.g4; ga.loss_partial = ws + w.loss_sum; ga.grad = grad; ga.count = (float)P;
   hipLaunchKernelGGL(onf_wgrad_gather_kernel, dim3((g.n_params + 255) / 256), dim3(256), 0, st, ga);
   NFOPP_HIP(hipGetLastError());
   return NFOPP_OK;

@@ -22,9 +22,13 @@
 // order, so L1 -> L2 -> L2^T -> L1^T never leaves registers.  tools/x32/emulate_x32.py checks every address formula
 // below, lane by lane, against a plain MLP (CPU).
 //
-// Modes: 0 forward + input gradient, 2 forward only.  The training pass (factors for the weight-gradient GEMMs) stays on
-// onf_split.hip.  Small launches (fewer samples than one 256-sample chunk per CU) also stay there: its 16-sample tiles
-// spread them over more CUs.
+// Modes: 0 forward + input gradient, 2 forward only, 1 the training pass of the ONF fit at scale (pass 1 of
+// csrc/onf_wgrad.hip; reference: loss.backward() of nfop/nerf_opt_planner.py:83-89).  The training pass runs the SAME four
+// GEMMs with dh2 = W3a [a2 > 0] unscaled -- everything behind it is linear in rho = (sigmoid(logit) - y) / count, which is
+// only known once the logit is complete -- and multiplies rho in where the factors are stored:  h1 | rho dh1 | rho de  by
+// feature / hidden-unit index ("x32 order": the accumulator layout gives every lane four consecutive positions per
+// register quad, i.e. one 16-byte store) plus the 48-byte record (u, 1, theta | rho | sign words of a2).  dW3[:100] =
+// sum_p rho_p relu(a2_p) is NOT accumulated here: it falls out of G2 in the gather kernel (WgradArgs::x32_order).
 #include <stdlib.h>
 #include <string.h>
 
@@ -360,7 +364,8 @@ template <int NKB, int MODE, int XT, int NT>
 __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelArgs a, const u32x4* __restrict__ img,
                                                          const u32x4* __restrict__ blob) {
   using C = Cfg<NKB>;
-  constexpr bool FWD_ONLY = MODE == 2;
+  constexpr bool FWD_ONLY = MODE == 2, TRAIN = MODE == 1;
+  static_assert(!TRAIN || NT == 1, "the training pass is written for one tile per wave");
   constexpr int CH = (XT / 64) * 32 * NT;   // samples per workgroup pass: NT 32-sample tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   {   // image -> LDS, four 16-byte pieces per thread in flight
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
 #endif
   };
 
-  const long long n_work = work_points(a);
+  const long long n_work = TRAIN ? a.n_points : work_points(a);
   const long long n_chunks = (n_work + CH - 1) / CH;
 
 #ifdef X32_PHASE_PROFILE
@@ -451,6 +456,11 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
   float nux = 0.f, nuy = 0.f, nth = 0.f;
   long long npidx = 0;
   bool have_next = false;
+  float loss_acc = 0.f;   // TRAIN
+  // TRAIN: 16-byte store of four consecutive positions of this lane's sample row (rows past P: dropped by the range check)
+  auto st4 = [](const __amdgpu_buffer_rsrc_t& r, int voff, float x0, float x1, float x2, float x3) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)}, r, voff, 0, 0);
+  };
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     float ux[NT], uy[NT], th[NT];
     long long pidx[NT];
@@ -464,7 +474,16 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       float x, y, ang;
       // NT = 1: this chunk (lower half) / the next one (upper half; past the last chunk: padding lanes, nothing stored)
       const long long p = NT == 1 ? (chunk + (g ? (long long)gridDim.x : 0)) * CH + wave * 32 + j : chunk * CH + wave * 64 + lane;
-      const long long row = load_point(a, n_work, p, 0, x, y, ang);
+      long long row;
+      if constexpr (TRAIN) {   // the fit's samples are explicit poses: the trajectory half of load_point (and the dozen scalar
+                               // registers of its arguments) is not part of this kernel
+        const bool ok = p < n_work;
+        const float* q = a.points + (ok ? p : n_work - 1) * a.geom.point_dim;
+        x = q[0]; y = q[1]; ang = a.geom.point_dim == 3 ? q[2] : 0.0f;
+        row = ok ? p : a.n_points;
+      } else {
+        row = load_point(a, n_work, p, 0, x, y, ang);
+      }
       const float sx = (x - geo.mean) / geo.sigma, sy = (y - geo.mean) / geo.sigma;
       const int rlo = (int)row, rhi = (int)(row >> 32);
       const float ox = __shfl_xor(sx, 32), oy = __shfl_xor(sy, 32), oa = __shfl_xor(ang, 32);
@@ -477,6 +496,35 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
         nux = g ? sx : ox; nuy = g ? sy : oy; nth = g ? ang : oa; npidx = g ? row : orow;
         have_next = true;
       }
+    }
+    // TRAIN: one buffer resource per stored array over the wave's 32 rows (scalar base, byte offsets j * row + 16 g + a
+    // compile-time constant), the label, and the sign words of a2 (positions 16 kb + 8 h + 4 g + r -> word 2 h + g, bit 4 kb + r)
+    // Each resource is built (a dozen scalar instructions, from an opaque copy of the wave index) where its phase starts:
+    // four descriptors alive across the chunk cost 16 scalar registers the kernel does not have.
+    int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto train_rsrc = [&](float* base, int row_floats) __attribute__((always_inline)) {
+      asm volatile("" : "+s"(wave_s));
+      long long rows = a.n_points - (chunk * CH + wave_s * 32);
+      rows = rows > 32 ? 32 : (rows < 0 ? 0 : rows);
+      const long long p0 = rows > 0 ? chunk * CH + wave_s * 32 : 0;
+      return __builtin_amdgcn_make_buffer_rsrc(base + p0 * row_floats, 0, (int)(rows * row_floats * 4), 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc((float*)nullptr, 0, 0, 0x00020000), r_dh1 = r_h1, r_de = r_h1, r_rec = r_h1;
+    // (the lane's byte offsets are formed from an opaque copy of the lane index where a phase needs them, like the LDS bases)
+    int vo_h = 0, vo_de = 0, vo_rec = 0;
+    auto train_offsets = [&]() __attribute__((always_inline)) {
+      asm volatile("" : "+v"(lane_v));
+      const int jj = lane_v & 31, gg = lane_v >> 5;
+      vo_h = jj * 448 + 16 * gg; vo_de = jj * (64 * NKB) + 16 * gg; vo_rec = jj * 48;
+    };
+    float yv = 0.f, rho[NT];
+    unsigned sgn[NT][2];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) { rho[T] = 1.0f; sgn[T][0] = sgn[T][1] = 0u; }
+    if constexpr (TRAIN) {
+      train_offsets();
+      r_rec = train_rsrc(a.ws_u, 12);
+      if (g == 0) st4(r_rec, vo_rec, ux[0], uy[0], 1.0f, th[0]);
     }
     u32x4 fh[2], fm[2];   // hi / mid fragments: this step and the next
 
@@ -630,20 +678,22 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
     for (int T = 0; T < NT; ++T) m1w[T][0] = m1w[T][1] = 0u;
     int w2f[2];
     bases_w2f(w2f);
+    if constexpr (TRAIN) { train_offsets(); r_h1 = train_rsrc(a.ws_h1, 112); }
     {
       u32x4 bb[2][NT][3];
-      float hv[NT][2];
+      float hv[NT][4];   // (TRAIN: the pairs alternate between [0..1] and [2..3]; every second pair completes a 16-byte store of h1)
       SplitState ss[NT];
       // relu + sign + split of one pair of block kb: 6 + 11 instructions per tile, the tiles' items alternating
       auto h1_item = [&](auto kbc, auto wc, u32x4 (&out)[NT][3]) __attribute__((always_inline)) {
         constexpr int kb = decltype(kbc)::value, T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
         if constexpr (w < 68) {
-          constexpr int p = w / 17, u = w % 17, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p;
-          if constexpr (u == 0) hv[T][0] = relu1(acc1[t][T][r0]);
-          if constexpr (u == 1) hv[T][1] = relu1(acc1[t][T][r0 + 1]);
-          if constexpr (u == 2) m1w[T][kb >> 2] = __builtin_amdgcn_alignbit(m1w[T][kb >> 2], 0u - __float_as_uint(hv[T][0]), 31);
-          if constexpr (u == 3) m1w[T][kb >> 2] = __builtin_amdgcn_alignbit(m1w[T][kb >> 2], 0u - __float_as_uint(hv[T][1]), 31);
-          if constexpr (u >= 4 && u < 15) split_item<u - 4>(ss[T], hv[T][0], hv[T][1], out[T], p);
+          constexpr int p = w / 17, u = w % 17, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p, h0 = TRAIN ? 2 * (p & 1) : 0;
+          if constexpr (u == 0) hv[T][h0] = relu1(acc1[t][T][r0]);
+          if constexpr (u == 1) hv[T][h0 + 1] = relu1(acc1[t][T][r0 + 1]);
+          if constexpr (u == 2) m1w[T][kb >> 2] = __builtin_amdgcn_alignbit(m1w[T][kb >> 2], 0u - __float_as_uint(hv[T][h0]), 31);
+          if constexpr (u == 3) m1w[T][kb >> 2] = __builtin_amdgcn_alignbit(m1w[T][kb >> 2], 0u - __float_as_uint(hv[T][h0 + 1]), 31);
+          if constexpr (u >= 4 && u < 15) split_item<u - 4>(ss[T], hv[T][h0], hv[T][h0 + 1], out[T], p);
+          if constexpr (TRAIN && u == 15 && (p & 1)) st4(r_h1, vo_h + 64 * kb + 32 * (p >> 1), hv[T][0], hv[T][1], hv[T][2], hv[T][3]);
         }
       };
       sfor<0, 68 * NT>([&](auto w) { h1_item(ic<0>{}, w, bb[0]); });
@@ -700,7 +750,9 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
     for (int T = 0; T < NT; ++T) lgs[T][0] = lgs[T][1] = 0.0f;
     int t2[2][2];
     bases_tr(std::false_type{}, t2);
+    if constexpr (TRAIN) yv = pidx[0] < a.n_points ? a.labels[pidx[0]] : 0.0f;   // (used behind this GEMM)
     {
+      constexpr int DH2_IP = TRAIN ? 14 : 12, DH2_PS = TRAIN ? 3 : 2;   // items per pair, per slot
       u32x4 bb[2][NT][3];
       f32x4 w3f[2];     // fp32 W3a of the block's 8 positions
       u32x4 w3c[3];     // its pre-split levels, B-fragment order
@@ -711,10 +763,14 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
         w3c[0] = lds128(lds, w3ll + 96 * kb); w3c[1] = lds128(lds, w3ll + 96 * kb + 16); w3c[2] = lds128(lds, w3ll + 96 * kb + 32);
       };
       // one pair of block kb: relu, sign mask, logit terms, masked level words: 12 instructions per tile, tiles alternating
+      // (TRAIN: + 2, the sign bits of a2 for the record, in front of the mask merge)
       auto dh2_item = [&](auto kbc, auto wc, u32x4 (&out)[NT][3]) __attribute__((always_inline)) {
         constexpr int kb = decltype(kbc)::value, T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
-        if constexpr (w < 48) {
-          constexpr int p = w / 12, u = w % 12, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p, e0 = 2 * p;
+        if constexpr (w < 4 * DH2_IP) {
+          constexpr int p = w / DH2_IP, u0 = w % DH2_IP, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p, e0 = 2 * p;
+          constexpr int u = !TRAIN ? u0 : (u0 < 8 ? u0 : (u0 < 10 ? 92 + u0 : u0 - 2));
+          if constexpr (u == 100) sgn[T][p >> 1] |= mk[T][0] & (1u << (4 * kb + (e0 & 3)));
+          if constexpr (u == 101) sgn[T][p >> 1] |= mk[T][1] & (1u << (4 * kb + (e0 & 3) + 1));
           if constexpr (u == 0) hv[T][0] = relu1(acc2[t][T][r0]);
           if constexpr (u == 1) hv[T][1] = relu1(acc2[t][T][r0 + 1]);
           if constexpr (u == 2) mk[T][0] = 0u - __float_as_uint(hv[T][0]);
@@ -730,7 +786,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
         }
       };
       dh2_load(0);
-      sfor<0, 48 * NT>([&](auto w) { dh2_item(ic<0>{}, w, bb[0]); });
+      sfor<0, 4 * DH2_IP * NT>([&](auto w) { dh2_item(ic<0>{}, w, bb[0]); });
       sfor<0, HK>([&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
         constexpr int Z = kb == 6;
@@ -750,7 +806,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           __builtin_amdgcn_sched_barrier(0);
           stepN<NT, 6 * NT * mt, kb == 0>(accd[mt], fh[mt & 1], fm[mt & 1], fl[(C::S_L2T + 4 * kb + mt) & (RL - 1)], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
-              sfor<0, 2>([&](auto i) { dh2_item(ic<kb + 1>{}, ic<2 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
+              sfor<0, DH2_PS>([&](auto i) { dh2_item(ic<kb + 1>{}, ic<DH2_PS * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
         });
       });
@@ -761,18 +817,36 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       logit[T] = lgs[T][0] + lgs[T][1] + (g == 1 ? skipv[T] : 0.0f);
       logit[T] += __shfl_xor(logit[T], 32);
     }
+    if constexpr (TRAIN) {   // BCE with logits (nerf_opt_planner.py:25,88): rho = (sigmoid(l) - y) / count; the record
+      train_offsets();
+      r_rec = train_rsrc(a.ws_u, 12);
+      r_dh1 = train_rsrc(a.ws_dh1, 112);
+      const bool t_valid = pidx[0] < a.n_points;
+      const float l = logit[0];
+      const float lp = fmaxf(l, 0.0f) - l * yv + log1pf(expf(-fabsf(l)));
+      rho[0] = t_valid ? (1.0f / (1.0f + expf(-l)) - yv) * a.inv_count : 0.0f;
+      if (t_valid && g == 0) loss_acc += lp * a.inv_count;
+      if (g == 0) st4(r_rec, vo_rec + 16, rho[0], 0.0f, 0.0f, 0.0f);
+      __builtin_amdgcn_raw_buffer_store_b32(sgn[0][0], r_rec, vo_rec + 32 + 4 * g, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(sgn[0][1], r_rec, vo_rec + 40 + 4 * g, 0, 0);
+    }
     X32_TICK(3)   // L2^T
 
     // ================================================================ dh1 = accd * [a1 > 0], dh1[skip row] = 1; three levels
     // Block 0 here; blocks 1..6 behind the steps of L1^T's first output tile (each step kb prepares block kb + 1).
     u32x4 dhl[HK][NT][3];
-    float dv[NT][2];
+    float dv[NT][2], dq[NT][4];
     SplitState dss[NT];
+    constexpr int DH1_IP = TRAIN ? 19 : 16, DH1_PS = TRAIN ? 13 : 11;   // items per pair; per slot behind L1^T's first tile
     // one pair of block kb: mask bits, masked values, (the skip row's constant), split: 16 instructions per tile
+    // (TRAIN: + 3, rho * dh1 and every second pair its 16-byte store; the GEMM itself goes on with the unscaled dh1)
     auto dh1_item = [&](auto kbc, auto wc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, T = decltype(wc)::value % NT, w = decltype(wc)::value / NT;
-      if constexpr (w < 64) {
-        constexpr int p = w / 16, u = w % 16, t = kb >> 1, e0 = 2 * p;
+      if constexpr (w < 4 * DH1_IP) {
+        constexpr int p = w / DH1_IP, u = w % DH1_IP, t = kb >> 1, e0 = 2 * p;
+        if constexpr (TRAIN && u == 16) dq[T][2 * (p & 1)] = dv[T][0] * rho[T];
+        if constexpr (TRAIN && u == 17) dq[T][2 * (p & 1) + 1] = dv[T][1] * rho[T];
+        if constexpr (TRAIN && u == 18 && (p & 1)) st4(r_dh1, vo_h + 64 * kb + 32 * (p >> 1), dq[T][0], dq[T][1], dq[T][2], dq[T][3]);
         constexpr int nbits = (kb >> 2) == 0 ? 32 : 8 * (HK - 4);   // pushes into this mask word
         constexpr int k0 = 8 * (kb & 3) + e0;
         if constexpr (u == 0) dv[T][0] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)m1w[T][kb >> 2], nbits - 1 - k0, 1));
@@ -780,10 +854,10 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
         if constexpr (u == 2) dv[T][0] = __uint_as_float(__float_as_uint(accd[t][T][8 * (kb & 1) + e0]) & __float_as_uint(dv[T][0]));
         if constexpr (u == 3) dv[T][1] = __uint_as_float(__float_as_uint(accd[t][T][8 * (kb & 1) + e0 + 1]) & __float_as_uint(dv[T][1]));
         if constexpr (u == 4 && kb == 6 && p == 0) dv[T][0] = g == 1 ? 1.0f : dv[T][0];   // position 100: d logit / d skip
-        if constexpr (u >= 5) split_item<u - 5>(dss[T], dv[T][0], dv[T][1], dhl[kb][T], p);
+        if constexpr (u >= 5 && u < 16) split_item<u - 5>(dss[T], dv[T][0], dv[T][1], dhl[kb][T], p);
       }
     };
-    sfor<0, 64 * NT>([&](auto w) { dh1_item(ic<0>{}, w); });
+    sfor<0, 4 * DH1_IP * NT>([&](auto w) { dh1_item(ic<0>{}, w); });
 
     X32_TICK(4)   // dh1
     // ================================================================ L1^T: din = W1ext^T dh1, then the chain rule
@@ -802,8 +876,8 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       u32x4 fhn, fmn;   // hi / mid fragments of the next tile's first step
       f32x4 tw[2][2];
       EvalState es[NT][2];
-      float de[NT][2];
-      int ep_ft = 0;
+      float de[NT][2], eq[NT][4];
+      int ep_ft = 0, ep_vo = 0;   // (TRAIN: byte offset of the epilogue tile in the sample's row of de)
       auto ep_load = [&](int pr) __attribute__((always_inline)) {   // pair pr = registers 2 pr, 2 pr + 1
         const int off = ep_ft + 128 * ((2 * pr) >> 2) + 16 * ((2 * pr) & 3);
         tw[pr & 1][0] = lds128f(lds, off);
@@ -818,14 +892,19 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           if constexpr (u == 0 && pr < 7 && T == 0) ep_load(pr + 1);
           if constexpr (st < 8) eval_item<st>(es[T][which], tw[pr & 1][which], ux[T], uy[T]);
           if constexpr (st == 8) de[T][which] = accp[T][r] * es[T][which].v;
-          if constexpr (st == 9) gxs[T][which] = fmaf(de[T][which], tw[pr & 1][which].x, gxs[T][which]);
-          if constexpr (st == 10) gys[T][which] = fmaf(de[T][which], tw[pr & 1][which].y, gys[T][which]);
+          if constexpr (!TRAIN) {
+            if constexpr (st == 9) gxs[T][which] = fmaf(de[T][which], tw[pr & 1][which].x, gxs[T][which]);
+            if constexpr (st == 10) gys[T][which] = fmaf(de[T][which], tw[pr & 1][which].y, gys[T][which]);
+          } else {   // the fit needs rho * de itself, not d logit / d pose
+            if constexpr (st == 9) eq[T][2 * (pr & 1) + which] = de[T][which] * rho[T];
+            if constexpr (st == 10 && which == 1 && (pr & 1)) st4(r_de, ep_vo + 32 * (pr >> 1), eq[T][0], eq[T][1], eq[T][2], eq[T][3]);
+          }
         }
       };
       // HOOK 1: the epilogue of tile mt - 1 behind this tile's steps;  2 (tile 0): dh1 block kb + 1 behind step kb
       auto l1t_tile = [&](auto hook_c, int mt, f32x16 (&acc)[NT]) __attribute__((always_inline)) {
         constexpr int HOOK = decltype(hook_c)::value;
-        if constexpr (HOOK == 1) { ep_ft = ftdl + 512 * (mt - 1); ep_load(0); }
+        if constexpr (HOOK == 1) { ep_ft = ftdl + 512 * (mt - 1); ep_vo = vo_de + 128 * (mt - 1); ep_load(0); }
         auto fetch = [&](int kbn, int mtn, int zn, u32x4& oh, u32x4& om) __attribute__((always_inline)) {
           const int off = 64 * mtn + (zn ? 0 : 16 * RS1 * kbn);
           oh = lds_tr(lds, O_W1H + t1[0][zn] + off, O_W1H + t1[1][zn] + off);
@@ -844,7 +923,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           stepN<NT, 6 * NT * kb, kb == 0>(acc, fh[kb & 1], fm[kb & 1], fl7[kb], dhl[kb], [&](auto slot) {
             if constexpr (HOOK == 1) sfor<0, 5>([&](auto i) { ep_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}); });
             if constexpr (HOOK == 2 && kb + 1 < HK)
-              sfor<0, 11>([&](auto i) { dh1_item(ic<kb + 1>{}, ic<11 * (decltype(slot)::value - 6 * NT * kb) + decltype(i)::value>{}); });
+              sfor<0, DH1_PS>([&](auto i) { dh1_item(ic<kb + 1>{}, ic<DH1_PS * (decltype(slot)::value - 6 * NT * kb) + decltype(i)::value>{}); });
           });
         });
       };
@@ -861,9 +940,15 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
             const float za = (th[T] + e.z) * e.x;
             arg = isa != 0.0f ? za : arg;
             const float d = acc[T][r] * sin_halfturns_hw(arg, e.w);
-            gxs[T][r & 1] = fmaf(d, isa != 0.0f ? 0.0f : e.x, gxs[T][r & 1]);
-            gys[T][r & 1] = fmaf(d, e.y, gys[T][r & 1]);
-            gt[T] = fmaf(d, isa != 0.0f ? e.x : 0.0f, gt[T]);
+            if constexpr (TRAIN) {
+              eq[T][r & 3] = d * rho[T];
+              // (an odd number of input blocks: the row of de ends in the middle of the last tile)
+              if ((r & 3) == 3 && 2 * mt + (r >> 3) < NKB) st4(r_de, vo_de + 128 * mt + 32 * (r >> 2), eq[T][0], eq[T][1], eq[T][2], eq[T][3]);
+            } else {
+              gxs[T][r & 1] = fmaf(d, isa != 0.0f ? 0.0f : e.x, gxs[T][r & 1]);
+              gys[T][r & 1] = fmaf(d, e.y, gys[T][r & 1]);
+              gt[T] = fmaf(d, isa != 0.0f ? e.x : 0.0f, gt[T]);
+            }
           }
       };
       {
@@ -871,6 +956,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
         fmn = lds_tr(lds, t1m[0][0], t1m[1][0]);
       }
       l1t_tile(ic<2>{}, 0, accp);
+      if constexpr (TRAIN) { train_offsets(); r_de = train_rsrc(a.ws_de, 16 * NKB); }
 #pragma unroll 1
       for (int mt = 1; mt < C::NMT; ++mt) {
         l1t_tile(ic<1>{}, mt, accc);
@@ -883,13 +969,21 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       for (int q = 0; q < LOOK; ++q) fl[q] = fl7[q];   // the first steps of the next chunk (fetched during the last tile)
     }
 #pragma unroll
-    for (int T = 0; T < NT; ++T) {
+    for (int T = 0; T < NT && !TRAIN; ++T) {
       float gx = gxs[T][0] + gxs[T][1], gy = gys[T][0] + gys[T][1], gth = gt[T];
       gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gth += __shfl_xor(gth, 32);
       if (a.out4 && g == 0 && pidx[T] < a.n_points)
         *reinterpret_cast<f32x4*>(a.out4 + pidx[T] * 4) = f32x4{logit[T], gx / geo.sigma, gy / geo.sigma, gth};
     }
     X32_TICK(6)   // last epilogue + output
+  }
+  if constexpr (TRAIN) {   // loss per wave, fixed order; the host sums 8 rows per workgroup whatever the shape
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o);
+    if (lane == 0) {
+      a.loss_partial[blockIdx.x * 8 + wave] = loss_acc;
+      if (XT == 256) a.loss_partial[blockIdx.x * 8 + 4 + wave] = 0.0f;
+    }
   }
 #ifdef X32_PHASE_PROFILE
   if (MODE == 0 && a.ws_u && (threadIdx.x == 0 || threadIdx.x == 256))
@@ -941,7 +1035,7 @@ static int buffers_for_stream(size_t bytes, hipStream_t stream, void** out, Slot
 }
 
 template <int NKB, int MODE, int XT, int NT>
-static int launch_shape(const OnfKernelArgs& a, hipStream_t stream) {
+static int launch_shape(const OnfKernelArgs& a, hipStream_t stream, int* grid_out = nullptr) {
   using C = Cfg<NKB>;
   constexpr int CH = (XT / 64) * 32 * NT;
   static bool attr_set[MAX_DEVICES] = {};
@@ -970,6 +1064,7 @@ static int launch_shape(const OnfKernelArgs& a, hipStream_t stream) {
   const long long n_chunks = (a.n_points + CH - 1) / CH;
   long long grid = query_cus();
   if (grid > n_chunks) grid = n_chunks;
+  if (grid_out) *grid_out = (int)grid;
 #ifdef X32_PHASE_PROFILE
   if (MODE == 0) {   // development only: synchronous, prints to stderr
     static float* dbg = nullptr;
@@ -1000,15 +1095,15 @@ static int launch_shape(const OnfKernelArgs& a, hipStream_t stream) {
 }
 
 template <int NKB, int MODE>
-static int launch_t(const OnfKernelArgs& a, hipStream_t stream) {
+static int launch_t(const OnfKernelArgs& a, hipStream_t stream, int* grid_out = nullptr) {
 #ifdef X32_THREADS   /* development A/B: one shape at every size (X32_TILES = 32-sample tiles per wave) */
 #ifndef X32_TILES
 #define X32_TILES 1
 #endif
-  return launch_shape<NKB, MODE, X32_THREADS, X32_TILES>(a, stream);
+  return launch_shape<NKB, MODE, X32_THREADS, MODE == 1 ? 1 : X32_TILES>(a, stream, grid_out);
 #else
-  return a.n_points < (long long)query_cus() * 256 ? launch_shape<NKB, MODE, 256, 1>(a, stream)
-                                                   : launch_shape<NKB, MODE, 512, 1>(a, stream);
+  return a.n_points < (long long)query_cus() * 256 ? launch_shape<NKB, MODE, 256, 1>(a, stream, grid_out)
+                                                   : launch_shape<NKB, MODE, 512, 1>(a, stream, grid_out);
 #endif
 }
 
@@ -1022,12 +1117,33 @@ bool onf_x32_supports(const OnfGeom& g) {
 
 int launch_onf_x32_kernel(const OnfKernelArgs& a, hipStream_t stream, bool forward_only) {
   if (a.n_points <= 0) return NFOPP_OK;
+#ifdef X32_ONLY_TRAIN   /* development: compile nothing but the training pass (register / spill studies) */
+  return NFOPP_ERR_ARG;
+#endif
   const int nkb = (a.geom.fin + 16) >> 4;
   switch (nkb) {
     case 14: return forward_only ? x32::launch_t<14, 2>(a, stream) : x32::launch_t<14, 0>(a, stream);
+#ifndef X32_ONLY_NKB14   /* development: compile the F = 208..223 instances only (a quarter of the build time) */
     case 13: return forward_only ? x32::launch_t<13, 2>(a, stream) : x32::launch_t<13, 0>(a, stream);
     case 8: return forward_only ? x32::launch_t<8, 2>(a, stream) : x32::launch_t<8, 0>(a, stream);
     case 7: return forward_only ? x32::launch_t<7, 2>(a, stream) : x32::launch_t<7, 0>(a, stream);
+#endif
+    default:
+      set_error("unsupported ONF feature dimension %d", a.geom.fin);
+      return NFOPP_ERR_ARG;
+  }
+}
+
+// training pass (pass 1 of csrc/onf_wgrad.hip), factors in x32 order
+int launch_onf_x32_train_kernel(const OnfKernelArgs& a, hipStream_t stream, int* grid_out) {
+  const int nkb = (a.geom.fin + 16) >> 4;
+  switch (nkb) {
+    case 14: return x32::launch_t<14, 1>(a, stream, grid_out);
+#ifndef X32_ONLY_NKB14
+    case 13: return x32::launch_t<13, 1>(a, stream, grid_out);
+    case 8: return x32::launch_t<8, 1>(a, stream, grid_out);
+    case 7: return x32::launch_t<7, 1>(a, stream, grid_out);
+#endif
     default:
       set_error("unsupported ONF feature dimension %d", a.geom.fin);
       return NFOPP_ERR_ARG;
