@@ -29,6 +29,8 @@ struct OnfKernelArgs {
   const float* labels;
   float inv_count;
   int aug_feature;   // zero-weight pad feature evaluated as cos(0) = 1: the "ones" column of the input matrix
+  // (slot orders below: the 16x16 kernels'; csrc/onf_x32.hip stores by index -- ones unit 101, rho row 100, ones feature fin,
+  //  rows of 16 * ((fin + 16) / 16) floats in ws_de, no g4 partials: csrc/onf_wgrad.hip, WgradArgs::x32_order)
   float* ws_h1;      // [P, 112]      relu(a1) in slot order (layout Q), ones at slot 16*6 + 1
   float* ws_dh1;     // [P, 112]      d loss / d a1, rho at slot 16*6 + 1
   float* ws_de;      // [P, 16*NKT]   d loss / d (encoding argument)

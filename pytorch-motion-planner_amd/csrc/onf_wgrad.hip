@@ -5,7 +5,9 @@
 // P = B * (N + 109) samples per step, BASELINE config 5).  Small P keeps the per-sample path of csrc/onf_train.hip.
 //
 // Pipeline (all reductions in a fixed order -> bitwise reproducible, no float atomics):
-//   1. onf_fwd_bwd_kernel<.., TRAIN> (csrc/onf_fused.hip): forward + backward per sample on the MFMA chain.  It writes
+//   1. pass 1, by matrix path: onf_x32_kernel<.., MODE 1> (csrc/onf_x32.hip; default, factors stored by index: "x32 order"),
+//      onf_split_kernel<.., MODE 1> or onf_fwd_bwd_kernel<.., TRAIN> (csrc/onf_split.hip / onf_fused.hip; factors in their
+//      slot orders): forward + backward per sample on the MFMA chain.  It writes
 //      only the factors pass 2 cannot rebuild cheaply --  h1 | dh1 | de  (slot order, with a ones column and a rho row
 //      so that bias and W3 gradients fall out of the same GEMMs) and a 48-byte record (u, rho, sign bits of a2) -- plus
 //      per-wave loss partials and per-wave partials of dW3[:100] = sum_p rho_p h2_p (h2 never leaves that kernel);

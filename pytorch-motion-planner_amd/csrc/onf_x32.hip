@@ -459,6 +459,10 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
   float loss_acc = 0.f;   // TRAIN
   // TRAIN: 16-byte store of four consecutive positions of this lane's sample row (rows past P: dropped by the range check)
   auto st4 = [](const __amdgpu_buffer_rsrc_t& r, int voff, float x0, float x1, float x2, float x3) __attribute__((always_inline)) {
+#ifdef X32_ABL_NOSTORE   /* timing-only ablation: the training pass without its factor stores (values kept alive) */
+    asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(voff));
+    return;
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)}, r, voff, 0, 0);
   };
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -506,7 +510,11 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       asm volatile("" : "+s"(wave_s));
       long long rows = a.n_points - (chunk * CH + wave_s * 32);
       rows = rows > 32 ? 32 : (rows < 0 ? 0 : rows);
+#ifdef X32_ABL_STORE_SAME   /* timing-only ablation (results wrong): every wave stores to the same few rows -- no HBM traffic */
+      const long long p0 = wave_s * 32;
+#else
       const long long p0 = rows > 0 ? chunk * CH + wave_s * 32 : 0;
+#endif
       return __builtin_amdgcn_make_buffer_rsrc(base + p0 * row_floats, 0, (int)(rows * row_floats * 4), 0x00020000);
     };
     __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc((float*)nullptr, 0, 0, 0x00020000), r_dh1 = r_h1, r_de = r_h1, r_rec = r_h1;
@@ -769,6 +777,8 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
         if constexpr (w < 4 * DH2_IP) {
           constexpr int p = w / DH2_IP, u0 = w % DH2_IP, t = kb >> 1, r0 = 8 * (kb & 1) + 2 * p, e0 = 2 * p;
           constexpr int u = !TRAIN ? u0 : (u0 < 8 ? u0 : (u0 < 10 ? 92 + u0 : u0 - 2));
+          // (the 28 bit constants live in scalar registers and push a few of those into spill lanes; pushing the bits in with
+          // v_alignbit instead frees them but moves the pressure to the vector file: 51 instead of 35 spilled registers, +3 %)
           if constexpr (u == 100) sgn[T][p >> 1] |= mk[T][0] & (1u << (4 * kb + (e0 & 3)));
           if constexpr (u == 101) sgn[T][p >> 1] |= mk[T][1] & (1u << (4 * kb + (e0 & 3) + 1));
           if constexpr (u == 0) hv[T][0] = relu1(acc2[t][T][r0]);
@@ -823,8 +833,13 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       r_dh1 = train_rsrc(a.ws_dh1, 112);
       const bool t_valid = pidx[0] < a.n_points;
       const float l = logit[0];
-      const float lp = fmaxf(l, 0.0f) - l * yv + log1pf(expf(-fabsf(l)));
-      rho[0] = t_valid ? (1.0f / (1.0f + expf(-l)) - yv) * a.inv_count : 0.0f;
+      // e = exp(-|l|) on the hardware exponential (relative error ~1e-7 |l|, where e matters |l| is small); sigmoid and
+      // softplus from it without cancellation -- the library expf / log1pf here cost two dozen spilled registers
+      const float e = __builtin_amdgcn_exp2f(-1.44269504f * fabsf(l));
+      const float inv = __builtin_amdgcn_rcpf(1.0f + e);
+      const float sg = l >= 0.0f ? inv : e * inv;
+      const float lp = fmaxf(l, 0.0f) - l * yv + 0.693147181f * __builtin_amdgcn_logf(1.0f + e);
+      rho[0] = t_valid ? (sg - yv) * a.inv_count : 0.0f;
       if (t_valid && g == 0) loss_acc += lp * a.inv_count;
       if (g == 0) st4(r_rec, vo_rec + 16, rho[0], 0.0f, 0.0f, 0.0f);
       __builtin_amdgcn_raw_buffer_store_b32(sgn[0][0], r_rec, vo_rec + 32 + 4 * g, 0, 0);

@@ -197,3 +197,54 @@ def _kink_free_err(got, want, allowed=3e-4):
     worst = np.sort(err)[::-1]
     k = int(allowed * len(err))          # 0 below 3 334 rows: every row is gated
     return float(worst[k])
+
+
+def _fit_grad(onf, x, y, matrix_path):
+    """gradient of the mean BCE loss through the at-scale path (pass 1 + weight-gradient GEMMs) on one matrix path"""
+    lib = _lib.load()
+    before = lib.nfopp_get_matrix_path()
+    _lib.check(lib.nfopp_set_matrix_path(matrix_path))
+    try:
+        P = x.shape[0]
+        c = onf.config_c()
+        need = lib.nfopp_onf_train_workspace_bytes(c, P)
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device="cuda")
+        grad = torch.zeros(onf.n_params + 2, device="cuda")
+        xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+        _lib.check(lib.nfopp_onf_train_grad_ex(c, _lib.ptr(onf.flat_parameters), _lib.ptr(xd), _lib.ptr(yd), P, 1.0 / P,
+                                               _lib.ptr(grad), _lib.ptr(ws), ws.numel() * 4, 2, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return grad.cpu().numpy()
+    finally:
+        _lib.check(lib.nfopp_set_matrix_path(before))
+
+
+@pytest.mark.parametrize("use_cos,angle,bias", [(True, True, True), (True, False, True), (False, True, False), (False, False, True)])
+def test_fit_gradient_every_feature_dimension_on_every_matrix_path_vs_oracle(use_cos, angle, bias):
+    """The fit's gradient at scale for F = 220 / 200 / 120 / 100 (the golden networks cover 220 and 100) on the three matrix
+    paths -- path 1 runs pass 1 on the 32x32 kernel with the factors stored by index (an odd and an even number of input
+    blocks, both workgroup shapes), paths 2 and 0 the 16x16 kernels with their slot orders -- against the numpy oracle
+    (nerf_opt_planner.py:83-89 restated), and bit for bit against a repeat."""
+    torch.random.manual_seed(5)
+    onf = nfopp.ONF(0.4, 2.5, use_cos=use_cos, use_normal_init=True, bias=bias, angle_encoding=angle).to("cuda")
+    cfg = orc.OnfConfig(0.4, 2.5, use_cos, bias, angle)
+    flat = onf.flat_parameters.cpu().numpy()
+    rng = np.random.default_rng(17)
+    d = 3 if angle else 2
+    for P in (4099, 70001):     # below / above one 256-sample chunk per CU
+        x = rng.uniform(-4, 6, (P, d)).astype(F32)
+        if angle:
+            x[:, 2] = rng.uniform(-3.3, 3.3, P)
+        y = (rng.uniform(size=P) < 0.35).astype(F32)
+        loss, _, gref = orc.onf_train_grads(flat, cfg, x, y)
+        scale = max(1.0, float(np.abs(gref).max()))
+        res = {}
+        for path in (1, 2, 0):
+            g = _fit_grad(onf, x, y, path)
+            assert g[-1] == P
+            assert abs(float(g[-2]) - float(loss)) < 5e-6 * max(1.0, abs(float(loss))), (path, P)
+            assert np.abs(g[:-2] - gref).max() < 2e-5 * scale, (path, P)
+            assert np.array_equal(g, _fit_grad(onf, x, y, path)), (path, P)
+            res[path] = g
+        for path in (1, 2):
+            assert np.abs(res[path][:-2] - res[0][:-2]).max() < 2e-5 * scale
