@@ -952,7 +952,7 @@ static WgradWs carve_wgrad(const OnfGeom& g, long long P, int nkt) {
   w.dh1 = o; o += P * HS;
   w.de = o; o += P * w.win;
   w.rec = o; o += P * 12;
-  w.loss = o; o += (long long)w.grid_cap * WAVES;   // pass 1 writes one row per wave
+  w.loss = o; o += (long long)w.grid_cap * (WAVES > 8 ? WAVES : 8);   // pass 1 writes one row per wave (onf_x32.hip: always 8 per workgroup)
   w.loss_sum = o; o += 4;
   w.g4_partial = o; o += (long long)w.grid_cap * WAVES * HS;
   w.g4 = o; o += HS;
@@ -1043,7 +1043,7 @@ int onf_train_grad_mfma(const OnfGeom& g, const float* params, const float* samp
                      ws + w.reduced, n_elems, grid);
   NFOPP_HIP(hipGetLastError());
   // loss and dW3[:100]: per-wave partials of pass 1
-  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.loss, ws + w.loss_sum, 1, grid_fwd * WAVES);
+  hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.loss, ws + w.loss_sum, 1, grid_fwd * (xo ? 8 : WAVES));
   NFOPP_HIP(hipGetLastError());
   if (!xo) {   // (x32 order: dW3[:100] comes out of G2 in the gather kernel)
     hipLaunchKernelGGL(onf_rows_reduce_kernel, dim3(HS), dim3(256), 0, st, ws + w.g4_partial, ws + w.g4, HS, grid_fwd * WAVES);

@@ -779,8 +779,13 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           constexpr int u = !TRAIN ? u0 : (u0 < 8 ? u0 : (u0 < 10 ? 92 + u0 : u0 - 2));
           // (the 28 bit constants live in scalar registers and push a few of those into spill lanes; pushing the bits in with
           // v_alignbit instead frees them but moves the pressure to the vector file: 51 instead of 35 spilled registers, +3 %)
+#ifndef X32_SGN_PUSH
           if constexpr (u == 100) sgn[T][p >> 1] |= mk[T][0] & (1u << (4 * kb + (e0 & 3)));
           if constexpr (u == 101) sgn[T][p >> 1] |= mk[T][1] & (1u << (4 * kb + (e0 & 3) + 1));
+#else   /* development A/B: bits pushed in from the low end, element (kb, r) ends at bit 27 - (4 kb + r) */
+          if constexpr (u == 100) sgn[T][p >> 1] = __builtin_amdgcn_alignbit(sgn[T][p >> 1], mk[T][0], 31);
+          if constexpr (u == 101) sgn[T][p >> 1] = __builtin_amdgcn_alignbit(sgn[T][p >> 1], mk[T][1], 31);
+#endif
           if constexpr (u == 0) hv[T][0] = relu1(acc2[t][T][r0]);
           if constexpr (u == 1) hv[T][1] = relu1(acc2[t][T][r0 + 1]);
           if constexpr (u == 2) mk[T][0] = 0u - __float_as_uint(hv[T][0]);
@@ -842,6 +847,9 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
       rho[0] = t_valid ? (sg - yv) * a.inv_count : 0.0f;
       if (t_valid && g == 0) loss_acc += lp * a.inv_count;
       if (g == 0) st4(r_rec, vo_rec + 16, rho[0], 0.0f, 0.0f, 0.0f);
+#ifdef X32_SGN_PUSH
+      sgn[0][0] = __builtin_bitreverse32(sgn[0][0]) >> 4; sgn[0][1] = __builtin_bitreverse32(sgn[0][1]) >> 4;
+#endif
       __builtin_amdgcn_raw_buffer_store_b32(sgn[0][0], r_rec, vo_rec + 32 + 4 * g, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b32(sgn[0][1], r_rec, vo_rec + 40 + 4 * g, 0, 0);
     }
