@@ -43,6 +43,10 @@ pts = traj[:, :-1].reshape(-1, 3).contiguous()
 def run(k):
     lib, mp = variants[k]
     lib.nfopp_set_matrix_path(mp)
+    if os.environ.get("AB_MODE") == "logits":        # forward only (nfopp_onf_eval_logits)
+        rc = lib.nfopp_onf_eval_logits(cfg, _lib.ptr(onf.flat_parameters), _lib.ptr(pts), pts.shape[0], _lib.ptr(out[k]), _lib.stream_ptr())
+        assert rc == 0, lib.nfopp_last_error()
+        return
     if POINTS:
         rc = lib.nfopp_onf_eval_points(cfg, _lib.ptr(onf.flat_parameters), _lib.ptr(pts), pts.shape[0], _lib.ptr(out[k]), _lib.stream_ptr())
         assert rc == 0, lib.nfopp_last_error()
