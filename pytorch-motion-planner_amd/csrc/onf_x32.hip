@@ -431,6 +431,8 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
   auto lo_frag = [&](int step) __attribute__((always_inline)) {
 #ifdef X32_ABL_NOLO   /* timing-only ablation (results wrong): no third-level loads */
     return u32x4{(unsigned)step, lane16, 0u, 0u};
+#elif defined(X32_ABL_LO_L1)   /* timing-only ablation (results wrong): the same loads from a 7 KB window -- served by the CU's L1 */
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane16, (step % 7) * 1024, 0));
 #else
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane16, step * 1024, 0));
 #endif
