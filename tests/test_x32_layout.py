@@ -1,4 +1,4 @@
-"""CPU: the index maps of the 32x32x16 ONF kernel (csrc/onf_x32.hip) without a GPU.
+"""CPU: the index maps of the 32x32x16 ONF kernel (csrc/onf_x32_impl.h) without a GPU.
 
 tools/x32/emulate_x32.py emulates the gfx950 MFMA operand / accumulator lane maps and both LDS reads (ds_read_b128 rows,
 ds_read_b64_tr_b16 transposed) and runs the kernel's address formulas, image packing, third-level fragment order, the
@@ -29,7 +29,7 @@ def test_fragment_addresses_chain_and_folded_rows(fin, capsys):
 
 def test_kernel_constants_match_the_emulated_layout_and_are_conflict_free():
     emu = _load("emulate_x32")
-    src = open(os.path.join(ROOT, "pytorch-motion-planner_amd", "csrc", "onf_x32.hip")).read()
+    src = open(os.path.join(ROOT, "pytorch-motion-planner_amd", "csrc", "onf_x32_impl.h")).read()
     consts = dict(re.findall(r"constexpr int (RS1|RS2|W1_ROWS|W2_ROWS|W1_ZERO|W2_ZERO|SKIP|ONES) = (\d+)", src.replace(",", ";\nconstexpr int")))
     for name in ("RS1", "RS2", "W1_ROWS", "W2_ROWS", "W1_ZERO", "W2_ZERO", "SKIP", "ONES"):
         assert int(consts[name]) == getattr(emu, name), name

@@ -1,4 +1,4 @@
-"""CPU emulation of the index maps of csrc/onf_x32.hip (the 32x32x16 ONF kernel).  Tools only, no GPU.
+"""CPU emulation of the index maps of csrc/onf_x32_impl.h (the 32x32x16 ONF kernel).  Tools only, no GPU.
 
 Emulates, lane by lane, the gfx950 semantics the kernel relies on
   * v_mfma_f32_32x32x16_bf16 operand / accumulator maps (cdna_hip_programming.md section 3)
@@ -114,7 +114,7 @@ def mfma32(A, B, C):
     return out
 
 
-# ---- the kernel's fragment fetches (address formulas as in onf_x32.hip) ---------------------------------------------
+# ---- the kernel's fragment fetches (address formulas as in onf_x32_impl.h) ---------------------------------------------
 def fwd_frag_w1(img1, kb, mt):
     A = np.zeros((64, 8))
     for l in range(64):
