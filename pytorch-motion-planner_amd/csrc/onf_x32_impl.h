@@ -289,7 +289,11 @@ __device__ __forceinline__ void eval_item(EvalState& s, const f32x4& tw, float u
   if constexpr (U == 4) s.r = fmaf(s.j, -6.28318548202514648f, s.arg);
   if constexpr (U == 5) s.r = fmaf(s.j, 1.74845553e-07f, s.r);
   if constexpr (U == 6) s.v = fmaf(s.r, 0.159154943f, tw.w);
+#ifdef X32_ABL_NOSIN   /* timing-only ablation (results wrong): a plain vector instruction in place of v_sin_f32 in the hooks */
+  if constexpr (U == 7) s.v = s.v * 0.5f;
+#else
   if constexpr (U == 7) s.v = __builtin_amdgcn_sinf(s.v);
+#endif
 }
 
 // Workgroup shapes: XT = 512 threads (two waves per SIMD, 256 samples per pass) fills the chip at scale; XT = 256 (one wave per
