@@ -231,7 +231,7 @@ def test_fit_gradient_every_feature_dimension_on_every_matrix_path_vs_oracle(use
     flat = onf.flat_parameters.cpu().numpy()
     rng = np.random.default_rng(17)
     d = 3 if angle else 2
-    for P in (4099, 70001):     # below / above one 256-sample chunk per CU
+    for P in (33, 4099, 70001):     # two partly filled tiles / below / above one 256-sample chunk per CU
         x = rng.uniform(-4, 6, (P, d)).astype(F32)
         if angle:
             x[:, 2] = rng.uniform(-3.3, 3.3, P)
