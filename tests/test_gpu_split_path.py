@@ -248,3 +248,78 @@ def test_fit_gradient_every_feature_dimension_on_every_matrix_path_vs_oracle(use
             res[path] = g
         for path in (1, 2):
             assert np.abs(res[path][:-2] - res[0][:-2]).max() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("use_cos,angle", [(True, True), (False, False)])
+def test_fit_pass1_factors_on_the_32x32_kernel_vs_oracle(use_cos, angle):
+    """White box: what pass 1 of the fit leaves in the workspace on matrix path 1 -- the contract between csrc/onf_x32_impl.h's
+    training mode and csrc/onf_wgrad.hip (WgradArgs::x32_order): rows  h1 [P,112] | rho*dh1 [P,112] | rho*de [P,16*NKB] |
+    record [P,12]  indexed by hidden unit / input feature, ones unit 101, rho row 100, sign bit of a2[s] in word (s>>2)&3 at
+    bit 4*(s>>4) + (s&3) -- against the oracle's intermediates (nerf_opt_planner.py:83-89 unrolled), for an even (F = 220) and
+    an odd (F = 100) number of input blocks and a ragged sample count."""
+    torch.random.manual_seed(9)
+    bias = True
+    onf = nfopp.ONF(0.4, 2.5, use_cos=use_cos, use_normal_init=True, bias=bias, angle_encoding=angle).to("cuda")
+    cfg = orc.OnfConfig(0.4, 2.5, use_cos, bias, angle)
+    flat = onf.flat_parameters.cpu().numpy()
+    rng = np.random.default_rng(23)
+    d, P = (3 if angle else 2), 4099
+    x = rng.uniform(-4, 6, (P, d)).astype(F32)
+    if angle:
+        x[:, 2] = rng.uniform(-3.3, 3.3, P)
+    y = (rng.uniform(size=P) < 0.35).astype(F32)
+    lib = _lib.load()
+    before = lib.nfopp_get_matrix_path()
+    _lib.check(lib.nfopp_set_matrix_path(1))
+    try:
+        c = onf.config_c()
+        need = lib.nfopp_onf_train_workspace_bytes(c, P)
+        ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device="cuda")
+        grad = torch.zeros(onf.n_params + 2, device="cuda")
+        xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+        _lib.check(lib.nfopp_onf_train_grad_ex(c, _lib.ptr(onf.flat_parameters), _lib.ptr(xd), _lib.ptr(yd), P, 1.0 / P,
+                                               _lib.ptr(grad), _lib.ptr(ws), ws.numel() * 4, 2, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.nfopp_set_matrix_path(before))
+    w = ws.cpu().numpy()
+    fin = (200 if use_cos else 100) + (20 if angle else 0)
+    win = 16 * ((fin + 16) // 16)
+    h1 = w[:P * 112].reshape(P, 112)
+    dh1 = w[P * 112:2 * P * 112].reshape(P, 112)
+    de = w[2 * P * 112:2 * P * 112 + P * win].reshape(P, win)
+    rec = w[2 * P * 112 + P * win:2 * P * 112 + P * win + P * 12].reshape(P, 12)
+    p = orc.unpack_params(flat, cfg)
+    logit, cch = orc._onf_forward_cache(p, cfg, x)
+    rho = ((orc.sigmoid(logit) - y) / F32(P)).astype(F32)
+    w3 = p["w3"][0]
+    dh2 = (rho[:, None] * w3[None, :100] * (cch["a2"] > 0)).astype(F32)
+    dh1_o = ((dh2 @ p["w2"]) * (cch["a1"] > 0)).astype(F32)
+    din = (dh1_o @ p["w1"] + rho[:, None] * w3[None, 100:]).astype(F32)
+    e = cch["e"]
+    de_o = np.concatenate([din[:, :100] * np.cos(e[:, :100]), -din[:, 100:200] * np.sin(e[:, 100:])], 1) if use_cos \
+        else din[:, :100] * np.cos(e)
+    if angle:
+        z, k = cch["z"], cfg.angle_dim
+        de_o = np.concatenate([de_o, din[:, cfg.n_enc:cfg.n_enc + k] * np.cos(z[:, :k]), -din[:, cfg.n_enc + k:] * np.sin(z[:, k:])], 1)
+
+    def close(got, want, tol):
+        return np.abs(got - want).max() <= tol * max(1e-30, float(np.abs(want).max()))
+
+    # rows whose pre-activations sit on a ReLU kink may differ by a whole unit between two correct evaluations: leave out
+    # the samples with any |a1| or |a2| below 1e-5 (a handful of 4099)
+    ok = (np.abs(cch["a1"]).min(1) > 1e-5) & (np.abs(cch["a2"]).min(1) > 1e-5)
+    assert ok.sum() > 0.98 * P
+    assert close(h1[:, :100], cch["h1"], 3e-6) and np.all(h1[:, 101] == 1.0)
+    assert close(rec[:, 4], rho, 3e-6) and close(dh1[:, 100], rho, 3e-6)
+    assert close(dh1[ok, :100], dh1_o[ok], 2e-5)
+    assert close(de[ok, :fin], de_o[ok], 2e-5)
+    assert np.all(de[:, fin + 1:] == 0.0)                       # pad positions
+    u = cch["u"]
+    assert np.array_equal(rec[:, 0], u[:, 0]) and np.array_equal(rec[:, 1], u[:, 1]) and np.all(rec[:, 2] == 1.0)
+    assert np.array_equal(rec[:, 3], x[:, 2] if angle else np.zeros(P, F32))
+    words = rec[:, 8:12].copy().view(np.uint32)
+    s = np.arange(100)
+    bits = (words[:, (s >> 2) & 3] >> (4 * (s >> 4) + (s & 3))) & 1
+    assert np.array_equal(bits[ok].astype(bool), cch["a2"][ok] > 0)
+    assert not (words >> 28).any()                              # nothing above the 28 positions of a word
