@@ -44,3 +44,22 @@ def test_kernel_constants_match_the_emulated_layout_and_are_conflict_free():
     # and the formulas themselves under the emulator's swizzles
     assert search.check(448, emu.swz1, 128, 224) == (1, 1)
     assert search.check(256, emu.swz2, 128, 112) == (1, 1)
+
+
+def test_second_layer_output_gradient_from_the_masked_outer_products():
+    """The identity csrc/onf_wgrad.hip's gather kernel uses in x32 order: with S[i][j] = sum_p rho_p [a2_p[i] > 0] h1_p[j]
+    (the weight-gradient GEMM G2 without W3a, ones column included), sum_p rho_p relu(a2_p)[i] = W2[i] . S[i] + b2[i] S[i][ones],
+    dW2 = W3a[:, None] * S and db2 = W3a * S[:, ones] -- h2 never has to be summed where it is formed."""
+    rng = np.random.default_rng(1)
+    P, H = 500, 100
+    w2, b2, w3a = rng.normal(size=(H, H)), rng.normal(size=H), rng.normal(size=H)
+    h1 = np.maximum(rng.normal(size=(P, H)), 0)
+    rho = rng.normal(size=P) / P
+    a2 = h1 @ w2.T + b2
+    mask = (a2 > 0).astype(np.float64)
+    h1e = np.concatenate([h1, np.ones((P, 1))], 1)
+    S = (rho[:, None] * mask).T @ h1e                        # [H, H + 1]
+    assert np.allclose((w2 * S[:, :H]).sum(1) + b2 * S[:, H], (rho[:, None] * np.maximum(a2, 0)).sum(0), rtol=1e-10, atol=1e-12)
+    dh2 = rho[:, None] * w3a[None] * mask
+    assert np.allclose(w3a[:, None] * S[:, :H], dh2.T @ h1, rtol=1e-10, atol=1e-12)
+    assert np.allclose(w3a * S[:, H], dh2.sum(0), rtol=1e-10, atol=1e-12)
