@@ -8,6 +8,8 @@ import importlib.util
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from conftest import ROOT
