@@ -34,6 +34,9 @@ traj = torch.rand(B, N, 3, device="cuda") * torch.tensor([100.0, 100.0, 6.0], de
 t = torch.zeros(B, N - 1, device="cuda")
 out = {k: torch.zeros(B, N - 1, 4, device="cuda") for k in variants}
 cfg = onf.config_c()
+if os.environ.get("AB_ZERO"):      # data-dependence of the time (power / clocks): all-zero weights, same instruction stream
+    with torch.no_grad():
+        onf.flat_parameters.zero_()
 
 
 POINTS = os.environ.get("AB_MODE") == "points"      # explicit poses (nfopp_onf_eval_points) instead of trajectory sampling
