@@ -264,6 +264,9 @@ def roofline(matrix_path, achieved, k1_ms, samples, traffic, traffic_source):
                             % ("32x32x16" if x32 else "16x16x32", SPLIT_PRODUCTS),
                     "pipe_peak": PEAK_BF16_MFMA_TFLOPS, "executed_tflops": achieved * SPLIT_PRODUCTS,
                     "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS})
+        if x32:   # not measured in this run: a replayed observation, like `traffic`, with its source named
+            out["clock_note"] = ("power-limited: `peak` assumes 2.4 GHz; under this kernel the engine clock is 1.9-2.05 GHz "
+                                 "(2.41 GHz on all-zero weights at the same cycle count), profiles/r03_clock_under_load.txt")
     else:
         out.update({"peak": PEAK_FP32_MFMA_TFLOPS, "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                     "kernel": "onf_fwd_bwd_kernel<14,2,0>"})
