@@ -34,6 +34,11 @@ traj = torch.rand(B, N, 3, device="cuda") * torch.tensor([100.0, 100.0, 6.0], de
 t = torch.zeros(B, N - 1, device="cuda")
 out = {k: torch.zeros(B, N - 1, 4, device="cuda") for k in variants}
 cfg = onf.config_c()
+if os.environ.get("AB_WBITS"):    # weights truncated to this many significant bits (8: the hi level alone, 16: hi + mid; the
+    bits = int(os.environ["AB_WBITS"])   # lower levels of the A operands are then all zero) -- which products cost the power
+    with torch.no_grad():
+        w = onf.flat_parameters.view(torch.int32)
+        w &= ~((1 << (24 - bits)) - 1)
 if os.environ.get("AB_ZERO"):      # data-dependence of the time (power / clocks): all-zero weights, same instruction stream
     with torch.no_grad():
         onf.flat_parameters.zero_()
