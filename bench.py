@@ -18,8 +18,15 @@ terms + H^-1 + Adam + multiplier ascent (stencil kernel), and the arc-length rep
 are resident in HBM before the timed region; the interpolation draws come from the in-kernel Philox stream.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          # no WORLD_SIZE in the env: starts its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # launched from outside: runs as one rank, as before
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE is a LAUNCHER: that process never makes a GPU call (it asserts
+so), starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+bench.py <same arguments>` as a child process group, relays rank 0's single JSON line to stdout and exits with the
+children's return code.  The line carries `backend` and `ranks_seen` = an all-reduce of ones over the process group the
+data path uses (== n_gpus, or the run did not span the ranks it claims).
 
 Rank 0 prints ONE JSON line.  Beside the contract's fields:
   roofline      fused ONF kernel: algorithmic fp32 FLOPs (131 400 per collision sample) over its HIP-event
@@ -28,7 +35,8 @@ Rank 0 prints ONE JSON line.  Beside the contract's fields:
                 `cpu_baseline_reference_faithful` = the eager-autograd single-trajectory restatement per core
                 (oracle/cpu_baselines.py, both validated against the reference's fixtures in tests/test_cpu_baselines.py;
                 timed in a child process that never touches the GPU).
-  parity        "final loss parity": (short) the first trajectories of THIS workload stepped by the GPU and by the numpy
+  parity        `ok` is a GATE: the run exits with code 4 when it is false (thresholds from the reference's own
+                conditioning, `parity_gate`).  "final loss parity": (short) the first trajectories of THIS workload stepped by the GPU and by the numpy
                 oracle (pinned to the reference) on the identical Philox draw stream from the same initial state --
                 waypoint and per-term loss differences; (final) total loss and collision-free rate after all W + K
                 steps, GPU vs the CPU restatement on the same sample, and the GPU's collision-free rate over the batch.
@@ -175,16 +183,39 @@ def short_parity(onf, starts, goals, n, sample, steps, device):
     diff = np.abs(got.astype(np.float64) - s["traj"])
     out = {"steps": steps, "trajectories": sample, "max_abs_traj": float(diff.max()),
            "p99_abs_traj": float(np.percentile(diff, 99)), "median_abs_traj": float(np.median(diff)),
-           "oracle_seconds": cpu_s,
-           "note": "same initial state, same Philox t stream; straight-line starts make single entries ill-conditioned "
-                   "under Adam (the reference restarted 1 ulp away moves by 2 lr = 0.1 in such entries after ONE step: tools/ref_conditioning.py -> tests/golden/g17_conditioning.npz, batch_k1_max)"}
+           "oracle_seconds": cpu_s}
     for tag, k in (("first_step", 0), ("last_step", steps - 1)):
         rel = {}
         for ours, theirs in TERM_PAIRS:
             a, b = float(np.sum(gterms[k][ours], dtype=np.float64)), float(np.sum(oterms[k][theirs], dtype=np.float64))
             rel[ours] = abs(a - b) / max(abs(b), 1e-6)
         out["loss_term_rel_diff_" + tag] = rel
+    out["gate"] = parity_gate(diff, out["loss_term_rel_diff_first_step"], steps)
     return out
+
+
+def parity_gate(diff, first_step_rel, steps):
+    """The short parity leg as a GATE (exit code, not a note).  From a straight-line start single waypoint entries are
+    ill-conditioned under Adam (zero-up-to-rounding gradient entries become +-lr moves), so the waypoint thresholds are
+    the REFERENCE's own spread when it is restarted one fp32 ulp away from itself on these settings
+    (tools/ref_conditioning.py -> tests/golden/g17_conditioning.npz, B = 4 straight-line problems, 12 steps:
+    `batch_k12_pct` = 90th percentile, `batch_k12_max` = maximum; columns xy, theta): median <= 1e-4, 99th percentile
+    <= 4 x batch_k12_pct, maximum <= 1.5 x batch_k12_max, xy and theta separately; and the per-term loss sums of the
+    FIRST step (no conditioning involved: same state, same draws) within 1e-5 relative."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g17_conditioning.npz"), allow_pickle=False)
+    pct, mx = z["batch_k12_pct"], z["batch_k12_max"]
+    checks = {}
+    worst_term = max(first_step_rel.values())
+    checks["first_step_terms_rel"] = {"value": worst_term, "limit": 1e-5, "ok": bool(worst_term <= 1e-5)}
+    if steps <= 12:   # the conditioning file measures 12 steps; a longer leg has no reference spread to be held against
+        for name, d, col in (("xy", diff[..., :2], 0), ("theta", diff[..., 2], 1)):
+            med, p99, top = float(np.median(d)), float(np.percentile(d, 99)), float(d.max())
+            lim = {"median": 1e-4, "p99": 4.0 * float(pct[col]), "max": 1.5 * float(mx[col])}
+            checks[name] = {"median": med, "p99": p99, "max": top, "limits": lim,
+                            "ok": bool(med <= lim["median"] and p99 <= lim["p99"] and top <= lim["max"])}
+    return {"ok": all(c["ok"] for c in checks.values()), "checks": checks,
+            "thresholds_from": "tests/golden/g17_conditioning.npz (batch_k12_pct, batch_k12_max): the reference restarted "
+                               "1 ulp away from itself, straight-line starts, bench-mr settings"}
 
 
 def final_parity(planner, checker, onf, starts, goals, n, total_steps, sample):
@@ -273,6 +304,74 @@ def roofline(matrix_path, achieved, k1_ms, samples, traffic, traffic_source):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and relay rank 0's JSON line.  This process must not have touched the GPU: a forked / spawned
+    rank inherits nothing from it, and the box forbids replacing a process that initialised HIP."""
+    if torch.cuda.is_initialized():
+        raise SystemExit("bench.py launcher: the parent process has initialised the GPU; refusing to start ranks")
+    port = os.environ.get("NFOPP_MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    line = None
+    try:
+        for out in proc.stdout:
+            if out.startswith("{") and '"metric"' in out:
+                line = out.strip()           # rank 0's result line (the last one wins; there is exactly one)
+            else:
+                sys.stderr.write(out)        # anything else a rank printed to stdout is diagnostics
+        rc = proc.wait()
+    except BaseException:
+        try:
+            os.killpg(proc.pid, 15)          # the exact process group started above
+        except OSError:
+            pass
+        raise
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        rc = 3                               # ranks exited cleanly but nobody printed the line
+    if torch.cuda.is_initialized():
+        raise SystemExit("bench.py launcher: the parent process initialised the GPU while waiting")
+    sys.exit(rc)
+
+
+def dry_run_rank(args, world, rank):
+    """`--dry-run-ranks`: the rank flow without the workload (no GPU call): rendezvous, one all-reduce of ones on the
+    gloo backend, rank 0 prints a line with n_gpus / ranks_seen.  tests/test_bench_launcher.py runs it on CPU."""
+    if world > 1:
+        torch.distributed.init_process_group("gloo")
+    seen = ranks_seen(world, "gloo", torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "waypoint-evals/sec", "value": None, "n_gpus": world, "ranks_seen": seen,
+                          "backend": "gloo", "dry_run": True, "gpu_initialised": bool(torch.cuda.is_initialized())}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def ranks_seen(world, backend, device):
+    """All-reduce of ones over the process group the data path uses: what the collective saw, not what was asked for."""
+    if world == 1:
+        return 1
+    one = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else "cpu")
+    torch.distributed.all_reduce(one)
+    return int(round(float(one.item())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,7 +388,19 @@ def main():
                     help="fused ONF kernel: bf16x3 split-precision MFMA on 32x32x16 tiles (library default, fp32-faithful), the "
                          "same arithmetic on round 2's 16x16x32 kernel, or fp32 MFMA; not given = leave the library's choice "
                          "(NFOPP_MATRIX_PATH) alone")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="rank flow only (rendezvous + all-reduce of ones on gloo, no GPU call, no workload): launcher test")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])     # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher around this process started a different number of "
+                         "ranks (plain `python bench.py --gpus %d` starts its own)" % (args.gpus, world, args.gpus))
+    if args.dry_run_ranks:
+        return dry_run_rank(args, world, rank)
     from nfopp import _lib
     lib = _lib.load()
     if args.matrix_path is not None:
@@ -297,12 +408,6 @@ def main():
     matrix_path = {1: "split", 2: "split16", 0: "fp32"}[lib.nfopp_get_matrix_path()]
     N = 512 if args.workload == "cfg5" else 256
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
     # one process per GPU; the modulo only matters for a rehearsal of the N-rank flow on a box with fewer GPUs
     # (NFOPP_DIST_BACKEND=gloo, several ranks sharing a card) -- on the benchmark node it is the identity
     dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -314,6 +419,7 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
         else:
             torch.distributed.init_process_group(backend)
+    seen = ranks_seen(world, backend, device)
 
     B = args.batch_per_gpu
     env = GridMap() if args.workload == "cfg4" else DiscMap()
@@ -372,6 +478,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    parity_failed = False
     if rank == 0:
         k1_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
         samples = (hi - lo) * (N - 1)
@@ -390,6 +497,7 @@ def main():
             "metric": "waypoint-evals/sec", "value": world * B * N * args.steps / elapsed, "unit": "waypoint-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ranks_seen": seen, "backend": (backend if world > 1 else "none (single process)"),
             "config": {"workload": workload, "trajectories_per_gpu": B, "waypoints": N, "global_batch": world * B,
                        "parallelism": "trajectory shards + one all-reduce of the 33163-float ONF gradient buffer per step"
                        if learn else "trajectory shards, no data-path collective",
@@ -404,13 +512,18 @@ def main():
             out["cpu_baseline_reference_faithful"] = cpu["reference_faithful"]
             out["cpu_host"] = {"visible_cores": cpu["host_cores"], "usable_cores": cpu["usable_cores"], "model": cpu["cpu_model"]}
             if not learn:   # frozen field: the CPU legs can replay the run exactly
-                out["parity"] = {"short": short_parity(onf, starts, goals, N, sample, args.parity_steps, device),
+                short = short_parity(onf, starts, goals, N, sample, args.parity_steps, device)
+                out["parity"] = {"ok": bool(short["gate"]["ok"] and finite), "short": short,
                                  "final": final_parity(planner, truth, onf, starts, goals, N, args.warmup + args.steps,
                                                        min(32, sample))}
+                parity_failed = not out["parity"]["ok"]
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if parity_failed:
+        sys.stderr.write("bench.py: parity gate FAILED (see the line's parity.short.gate)\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":
