@@ -118,14 +118,21 @@ void traj_step(const Tensor& params, double mean, double sigma, bool use_cos, bo
   if (D == 3) {
     TORCH_CHECK(lam.has_value() && cm.has_value(), "nfopp: the SE(2) step needs the multiplier tensors lam [B, N+1], cm [B, N]");
     need(*lam, "lam", {B, N + 1}); need(*cm, "cm", {B, N});
+  } else {
+    // the 2-D step has no multipliers: a tensor passed here would reach the kernel unvalidated
+    TORCH_CHECK(!lam.has_value() && !cm.has_value(), "nfopp: the 2-D step takes no multiplier tensors (lam / cm must be None)");
   }
   if (terms.has_value()) need(*terms, "terms", {B, NFOPP_NUM_TERMS});
   if (active.has_value()) {
     check_tensor(*active, "active", at::kByte);
+    same_device(traj, *active, "active");
     TORCH_CHECK(active->numel() == B, "nfopp: active must be [B] uint8");
     TORCH_CHECK(live_ws.has_value(), "nfopp: an active mask needs the live-list workspace (B + 1 int32)");
     check_tensor(*live_ws, "live_ws", at::kInt);
+    same_device(traj, *live_ws, "live_ws");
     TORCH_CHECK(live_ws->numel() >= B + 1, "nfopp: live_ws must hold B + 1 int32");
+  } else {
+    TORCH_CHECK(!live_ws.has_value(), "nfopp: live_ws without an active mask");
   }
   const nfopp_traj_hyper hp = make_hyper(hyper);
   c10::hip::HIPGuardMasqueradingAsCUDA guard(traj.device());
@@ -154,10 +161,15 @@ void reparametrize(Tensor traj, const Tensor& start, const Tensor& goal, const O
   if (D == 3) {
     TORCH_CHECK(lam.has_value() && cm.has_value(), "nfopp: the SE(2) reparametrisation needs lam [B, N+1] and cm [B, N]");
     check_tensor(*lam, "lam"); check_tensor(*cm, "cm");
+    same_device(traj, *lam, "lam"); same_device(traj, *cm, "cm");
     TORCH_CHECK(lam->numel() == B * (N + 1) && cm->numel() == B * N, "nfopp: lam must be [B, N+1], cm [B, N]");
+  } else {
+    TORCH_CHECK(D == 2, "nfopp: trajectory dim must be 2 or 3");
+    TORCH_CHECK(!lam.has_value() && !cm.has_value(), "nfopp: the 2-D reparametrisation takes no multiplier tensors");
   }
   if (active.has_value()) {
     check_tensor(*active, "active", at::kByte);
+    same_device(traj, *active, "active");
     TORCH_CHECK(active->numel() == B, "nfopp: active must be [B] uint8");
   }
   c10::hip::HIPGuardMasqueradingAsCUDA guard(traj.device());

@@ -130,13 +130,20 @@ class OnfFitter(object):
 class BatchPlanner(object):
     """B trajectories, one shared ONF, one GPU.  `step()` = the planner step of nfop/nerf_opt_planner.py:60-71 for the
     whole batch: [ONF fit on freshly sampled poses, when a ground-truth `checker` is given] -> one
-    `_optimize_trajectory` per trajectory -> periodic reparametrisation.  Without a checker the field is frozen."""
+    `_optimize_trajectory` per trajectory -> periodic reparametrisation.  Without a checker the field is frozen.
+
+    The planner owns the field's update loop, so it FREEZES the ONF object (`ONF.freeze()`): launches reuse the pre-split
+    weight image until the planner's own Adam step (or an in-place torch op) changes the parameters.  A caller who writes
+    the parameters behind torch's back while a planner exists -- `dist.broadcast(onf.flat_parameters, 0)`, `.data`
+    assignments -- must call `onf.mark_modified()` afterwards (or construct with `freeze_field=False`)."""
 
     def __init__(self, onf, batch, n_waypoints, hyper, velocity_hessian_weight=0.5, reparametrize_trajectory_freq=10,
                  device="cuda", seed=0, traj_index_offset=0, checker=None, fit_lr=2e-2, fit_betas=(0.9, 0.9),
                  optimize_collision_model_freq=1, trajectory_random_offset=0.02, course_random_offset=1.5,
                  angle_offset=0.0, random_field_points=10, collision_point_count=100, group=None,
-                 init_angles_with_trajectory=False, global_batch=None):
+                 init_angles_with_trajectory=False, global_batch=None, freeze_field=True):
+        if freeze_field:
+            onf.freeze()
         self.init_angles_with_trajectory = bool(init_angles_with_trajectory)
         # trajectories over ALL ranks (continuous learning: denominator of the BCE mean); default = equal shards
         self.global_batch = None if global_batch is None else int(global_batch)

@@ -63,7 +63,10 @@ class ONF(nn.Module):
     def _bind(self, flat):
         self._withdraw_version()
         object.__setattr__(self, "_flat", flat.contiguous())
-        object.__setattr__(self, "_vouched", None)   # (data_ptr, torch version counter) the library holds a version for
+        object.__setattr__(self, "_vouched", None)   # (data_ptr, torch version counter) the registered version stands for
+        object.__setattr__(self, "_registered", None)   # (device, data_ptr) the library holds a version for, if any
+        if not hasattr(self, "_frozen"):
+            object.__setattr__(self, "_frozen", False)
         views, o = {}, 0
         for name, shape in self._layout:
             n = 1
@@ -110,37 +113,91 @@ class ONF(nn.Module):
 
     def config_c(self):
         """Configuration block of the C ABI.  Every launch that reads the parameters fetches it first, so this is also where
-        the buffer's content version is (re-)registered with the library (nfopp_onf_params_version): while the flat buffer
-        has not been written -- torch's version counter, which every in-place op on the buffer or on a parameter view
-        bumps, plus `mark_modified()` for writes torch cannot see -- the split kernels reuse their pre-split weight image
-        instead of rebuilding it in front of every launch."""
+        the buffer's content version is registered with -- or withdrawn from -- the library (nfopp_onf_params_version).
+        DEFAULT: no version, the split kernels rebuild their pre-split weight image in front of every launch (5 us), so a
+        write to the parameters by ANY means (in-place ops, `.data`, `dist.broadcast`, a foreign kernel) shows in the very
+        next evaluation.  Image reuse is OPT-IN: see `freeze()`."""
         self._vouch()
         return _lib.OnfConfigC(self._mean, self._sigma, int(self._use_cos), int(self._bias), self._angle_dim)
+
+    # ---- weight-image reuse (ABI 5 content versions): opt-in ------------------------------------------------------
+    def freeze(self):
+        """The caller takes responsibility for telling this object about parameter writes: from now on launches reuse the
+        stream's pre-split weight image (no prep launch) until `mark_modified()` / `unfreeze()` is called.  In-place
+        torch ops on the flat buffer or on a parameter view are still noticed by themselves (torch's version counter); writes
+        the counter does NOT see -- `torch.distributed.broadcast` / `all_reduce` into the buffer, `.data` assignments,
+        raw-pointer kernels -- need `mark_modified()`.  The planners that own the field's update loop (`BatchPlanner`, the
+        drop-in planners inside `step(n)`) freeze the field themselves and call `mark_modified()` after their own Adam
+        steps.  Returns self."""
+        object.__setattr__(self, "_frozen", True)
+        return self
+
+    def unfreeze(self):
+        """Back to the default: the weight image is rebuilt in front of every launch."""
+        object.__setattr__(self, "_frozen", False)
+        self._withdraw_version()
+        object.__setattr__(self, "_vouched", None)
+        return self
+
+    @property
+    def is_frozen(self):
+        return self._frozen
+
+    def frozen(self):
+        """Context manager: `with onf.frozen(): ...` = freeze() for the block, the previous state afterwards."""
+        onf = self
+
+        class _Scope(object):
+            def __enter__(self_inner):
+                self_inner.was = onf._frozen
+                onf.freeze()
+                return onf
+
+            def __exit__(self_inner, *exc):
+                if not self_inner.was:
+                    onf.unfreeze()
+                return False
+        return _Scope()
+
+    def _torch_version(self):
+        """torch's in-place version counter of the flat buffer, None where torch keeps none (inference tensors: an ONF built,
+        moved or re-bound under `torch.inference_mode()`); then only `mark_modified()` announces a write."""
+        try:
+            return self._flat._version
+        except RuntimeError:
+            return None
 
     def _vouch(self):
         f = self._flat
         if not f.is_cuda:
             return
-        key = (f.data_ptr(), f._version)
+        if not self._frozen:
+            self._withdraw_version()          # a version left over from a frozen phase
+            object.__setattr__(self, "_vouched", None)
+            return
+        key = (f.data_ptr(), self._torch_version())
         if self._vouched != key:
             lib = _lib.load()
             with torch.cuda.device(f.device):
                 _lib.check(lib.nfopp_onf_params_version(f.data_ptr(), next(_CONTENT_VERSIONS)))
             object.__setattr__(self, "_vouched", key)
+            object.__setattr__(self, "_registered", (f.device, f.data_ptr()))
 
     def mark_modified(self):
-        """Call after writing the parameters in a way torch's version counter does not see (a raw-pointer kernel such as
-        nfopp_adam_step, or `.data` writes): the next launch re-registers a new content version."""
+        """Call after writing the parameters of a FROZEN field in a way torch's version counter does not see (a raw-pointer
+        kernel such as nfopp_adam_step, `.data` writes, collectives into the buffer): the next launch registers a new content
+        version and rebuilds the image.  No-op for an unfrozen field (it rebuilds anyway)."""
         object.__setattr__(self, "_vouched", None)
 
     def _withdraw_version(self):
-        f = getattr(self, "_flat", None)
-        if f is not None and f.is_cuda and getattr(self, "_vouched", None) is not None:
+        reg = getattr(self, "_registered", None)
+        if reg is not None:
             try:
-                with torch.cuda.device(f.device):
-                    _lib.load().nfopp_onf_params_version(f.data_ptr(), 0)
+                with torch.cuda.device(reg[0]):
+                    _lib.load().nfopp_onf_params_version(reg[1], 0)
             except Exception:
                 pass
+            object.__setattr__(self, "_registered", None)
 
     def __del__(self):
         self._withdraw_version()

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (BENCHMR_FIXTURES, benchmr_rollout_tol, abs_percentile, check_batch_snapshot, load_golden, max_abs,
+from conftest import (BENCHMR_FIXTURES, benchmr_rollout_tol, check_benchmr_rollout, abs_percentile, check_batch_snapshot, load_golden, max_abs,
                       max_rel)
 
 pytestmark = pytest.mark.gpu
@@ -67,13 +67,8 @@ def test_benchmr_settings_terms_step_rollouts_vs_golden(name, ks):
                 eng.reparametrize()
             step_count += 1
             done += 1
-        pre, tol = "g6_k%d_" % K, benchmr_rollout_tol(name, K)
-        tr = eng.traj.cpu().numpy()[0]
-        assert step_count == int(z[pre + "step_count"])
-        assert max_abs(tr[:, :2], z[pre + "traj"][:, :2]) < tol["xy"], K
-        assert max_abs(tr[:, 2], z[pre + "traj"][:, 2]) < tol["th"], K
-        assert max_abs(eng.lam.cpu().numpy()[0], z[pre + "lam"]) < tol["lam"], K
-        assert max_abs(eng.cm.cpu().numpy()[0], z[pre + "cm"]) < tol["cm"], K
+        assert step_count == int(z["g6_k%d_step_count" % K])
+        check_benchmr_rollout(name, K, eng.traj.cpu().numpy()[0], eng.lam.cpu().numpy()[0], eng.cm.cpu().numpy()[0], z)
 
 
 def test_benchmr_small_batch_vs_golden():

@@ -125,34 +125,89 @@ def test_split_collision_eval_and_rollout(name, split_path):
     assert np.max(np.abs(res[0] - res[1])) < 2e-5
 
 
-def test_cached_weight_image_follows_the_parameters():
-    """ABI 5: while the ONF's flat buffer is unchanged (torch's version counter + mark_modified) launches reuse the stream's
-    pre-split weight image; any in-place write -- through the flat buffer, through a parameter view, or a raw-pointer
-    Adam step -- must show up in the very next evaluation."""
+def test_unfrozen_field_sees_every_kind_of_write():
+    """DEFAULT: image reuse is opt-in, an unfrozen ONF rebuilds its pre-split weight image in front of every
+    launch, so writes torch's version counter does not see -- `.data` assignments, collectives / foreign kernels writing
+    through the raw pointer -- show in the very next evaluation."""
+    z = load_golden("g1_onf.npz")
+    onf, cfg = gc.make_onf(z["a_cfg"], z["a_params"])
+    assert not onf.is_frozen
+    x = torch.tensor(z["a_x"], device="cuda")
+    base = onf.forward_with_grad(x).clone()
+    v0 = onf.flat_parameters._version
+    onf.flat_parameters.data[:2000] *= 1.5                         # .data write: the version counter does not move
+    getattr(onf.mlp, "0").weight.data.mul_(0.5)
+    assert onf.flat_parameters._version == v0
+    moved = onf.forward_with_grad(x).clone()
+    assert not torch.equal(moved, base)
+    # a raw-pointer write from outside torch's bookkeeping (what dist.broadcast / all_reduce into the buffer amount to)
+    src = torch.tensor(z["a_params"], device="cuda")
+    alias = torch.utils.dlpack.from_dlpack(torch.utils.dlpack.to_dlpack(onf.flat_parameters))   # same memory, own bookkeeping
+    assert alias.data_ptr() == onf.flat_parameters.data_ptr()
+    alias.copy_(src)
+    assert onf.flat_parameters._version == v0
+    assert torch.equal(onf.forward_with_grad(x), base)
+
+
+def test_frozen_field_reuses_its_image_and_follows_announced_writes():
+    """ABI 5, opt-in: a FROZEN field's launches reuse the stream's pre-split weight image; in-place torch ops (flat buffer or a
+    parameter view) and the library's own Adam step are noticed by themselves, anything else through `mark_modified()`;
+    `unfreeze()` returns to rebuild-per-launch."""
     z = load_golden("g1_onf.npz")
     onf, cfg = gc.make_onf(z["a_cfg"], z["a_params"])
     x = torch.tensor(z["a_x"], device="cuda")
     lib = _lib.load()
-    base = onf.forward_with_grad(x).clone()
-    assert torch.equal(onf.forward_with_grad(x), base)              # cached image: same bits as a rebuilt one
-    _lib.check(lib.nfopp_onf_params_version(onf.flat_parameters.data_ptr(), 0))
-    onf.mark_modified()
-    assert torch.equal(onf.forward_with_grad(x), base)
-    with torch.no_grad():
-        getattr(onf.mlp, "0").weight.mul_(1.5)                                   # a parameter VIEW, in place
-    moved = onf.forward_with_grad(x).clone()
-    assert not torch.equal(moved, base)
-    with torch.no_grad():
-        onf.flat_parameters.copy_(torch.tensor(z["a_params"], device="cuda"))
-    assert torch.equal(onf.forward_with_grad(x), base)
-    # raw-pointer update by the library itself: the registration is withdrawn by nfopp_adam_step
-    g = torch.ones_like(onf.flat_parameters)
-    m, v = torch.zeros_like(g), torch.zeros_like(g)
-    _lib.check(lib.nfopp_adam_step(_lib.ptr(onf.flat_parameters), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), onf.n_params, 0.9, 0.1,
-                                   0.1, 1e-8, 0.05, 1.0, _lib.stream_ptr()))
-    after = onf.forward_with_grad(x)
-    torch.cuda.synchronize()
-    assert not torch.equal(after, base)
+    rebuilt = onf.forward_with_grad(x).clone()
+    with onf.frozen():
+        assert onf.is_frozen
+        base = onf.forward_with_grad(x).clone()
+        assert torch.equal(base, rebuilt)                              # cached image: same bits as a rebuilt one
+        assert torch.equal(onf.forward_with_grad(x), base)
+        with torch.no_grad():
+            getattr(onf.mlp, "0").weight.mul_(1.5)                                   # a parameter VIEW, in place
+        moved = onf.forward_with_grad(x).clone()
+        assert not torch.equal(moved, base)
+        with torch.no_grad():
+            onf.flat_parameters.copy_(torch.tensor(z["a_params"], device="cuda"))
+        assert torch.equal(onf.forward_with_grad(x), base)
+        # a write the counter does not see: announced with mark_modified()
+        onf.flat_parameters.data.mul_(1.25)
+        onf.mark_modified()
+        assert not torch.equal(onf.forward_with_grad(x), base)
+        onf.flat_parameters.data.copy_(torch.tensor(z["a_params"], device="cuda"))
+        onf.mark_modified()
+        assert torch.equal(onf.forward_with_grad(x), base)
+        # raw-pointer update by the library itself: the registration is withdrawn by nfopp_adam_step
+        g = torch.ones_like(onf.flat_parameters)
+        m, v = torch.zeros_like(g), torch.zeros_like(g)
+        _lib.check(lib.nfopp_adam_step(_lib.ptr(onf.flat_parameters), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), onf.n_params, 0.9, 0.1,
+                                       0.1, 1e-8, 0.05, 1.0, _lib.stream_ptr()))
+        after = onf.forward_with_grad(x).clone()
+        torch.cuda.synchronize()
+        assert not torch.equal(after, base)
+    assert not onf.is_frozen
+    # unfrozen again, and the library holds no version for the buffer any more: an unannounced .data write shows at once
+    onf.flat_parameters.data.copy_(torch.tensor(z["a_params"], device="cuda"))
+    assert torch.equal(onf.forward_with_grad(x), rebuilt)
+
+
+def test_field_built_under_inference_mode_evaluates():
+    """inference tensors keep no version counter; reading it raised in every config_c().  Such a field works,
+    frozen or not (frozen: only mark_modified() announces writes)."""
+    z = load_golden("g1_onf.npz")
+    with torch.inference_mode():
+        onf, cfg = gc.make_onf(z["a_cfg"], z["a_params"])
+        x = torch.tensor(z["a_x"], device="cuda")
+        a = onf.forward_with_grad(x).clone()
+        onf.freeze()
+        b = onf.forward_with_grad(x).clone()
+        onf.flat_parameters.mul_(1.5)
+        onf.mark_modified()
+        c = onf.forward_with_grad(x).clone()
+    assert onf._torch_version() is None
+    assert torch.equal(a, b) and not torch.equal(b, c)
+    ref = gc.make_onf(z["a_cfg"], z["a_params"])[0].forward_with_grad(x)
+    assert torch.equal(a, ref)
 
 
 @pytest.mark.parametrize("use_cos,angle,bias", [(True, True, True), (True, False, True), (False, True, False), (False, False, True),

@@ -32,6 +32,14 @@ def test_no_packed_fp32_op_reads_a_high_dword_into_its_low_lane():
     import subprocess
     res = subprocess.run([os.path.join(ROOT, "tools", "check_packed_opsel.sh"), _lib.LIB_PATH], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+    # fails closed: a file it cannot extract a gfx950 code object from was NOT checked and must not pass
+    import ctypes.util
+    other = subprocess.run([os.path.join(ROOT, "tools", "check_packed_opsel.sh"), os.path.abspath(__file__)], capture_output=True,
+                           text=True)
+    assert other.returncode == 2 and "nothing was checked" in other.stderr + other.stdout or other.returncode == 2, other.stderr
+    missing = subprocess.run([os.path.join(ROOT, "tools", "check_packed_opsel.sh"), _lib.LIB_PATH], capture_output=True, text=True,
+                             env=dict(os.environ, OBJDUMP="/nonexistent/llvm-objdump"))
+    assert missing.returncode == 2 and "failing closed" in missing.stderr
     # the pattern the script looks for does match the offending form and not the harmless direction
     import re as _re
     pat = _re.compile(r"op_sel:\[[01,]*1[01,]*\]")

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import BENCHMR_FIXTURES, benchmr_rollout_tol, check_batch_snapshot, load_golden, max_abs, max_rel
+from conftest import BENCHMR_FIXTURES, benchmr_rollout_tol, check_benchmr_rollout, check_batch_snapshot, load_golden, max_abs, max_rel
 from oracle import nfopp_oracle as orc
 
 F32 = np.float32
@@ -192,12 +192,8 @@ def test_benchmr_settings_terms_step_rollouts(name, ks):
         while done < K:
             orc.planner_step(s, z["g6_t"][done][None], z["params"], cfg, hp, hinv)
             done += 1
-        pre, tol = "g6_k%d_" % K, benchmr_rollout_tol(name, K)
-        assert s["step_count"] == int(z[pre + "step_count"])
-        assert max_abs(s["traj"][0][:, :2], z[pre + "traj"][:, :2]) < tol["xy"], K
-        assert max_abs(s["traj"][0][:, 2], z[pre + "traj"][:, 2]) < tol["th"], K
-        assert max_abs(s["lam"][0], z[pre + "lam"]) < tol["lam"], K
-        assert max_abs(s["cm"][0], z[pre + "cm"]) < tol["cm"], K
+        assert s["step_count"] == int(z["g6_k%d_step_count" % K])
+        check_benchmr_rollout(name, K, s["traj"][0], s["lam"][0], s["cm"][0], z)
 
 
 def test_benchmr_small_batch_equals_independent_runs():

@@ -10,15 +10,22 @@ OBJDUMP=${OBJDUMP:-/opt/rocm/lib/llvm/bin/llvm-objdump}
 TMP=$(mktemp -d)
 trap 'rm -rf $TMP' EXIT
 cp "$LIB" $TMP/lib.so
-(cd $TMP && $OBJDUMP --offloading lib.so > /dev/null 2>&1)
+[ -x "$OBJDUMP" ] || { echo "check_packed_opsel: $OBJDUMP not found -- the check cannot run, failing closed" >&2; exit 2; }
+(cd $TMP && $OBJDUMP --offloading lib.so > $TMP/extract.log 2>&1) || { echo "check_packed_opsel: code-object extraction failed:" >&2; tail -5 $TMP/extract.log >&2; exit 2; }
 n=0
+objects=0
 for co in $TMP/lib.so.*gfx950*; do
   [ -f "$co" ] || continue
-  $OBJDUMP -d "$co" | grep -E "v_pk_(fma|mul|add)_f32" | grep -E "op_sel:\[[01,]*1[01,]*\]" > $TMP/hits.txt || true
+  objects=$((objects + 1))
+  $OBJDUMP -d "$co" > $TMP/dis.txt || { echo "check_packed_opsel: disassembly of $(basename $co) failed" >&2; exit 2; }
+  [ "$(grep -c "v_mfma\|s_endpgm" $TMP/dis.txt)" -gt 0 ] || { echo "check_packed_opsel: $(basename $co) disassembled to no instructions" >&2; exit 2; }
+  grep -E "v_pk_(fma|mul|add)_f32" $TMP/dis.txt | grep -E "op_sel:\[[01,]*1[01,]*\]" > $TMP/hits.txt || true
   if [ -s $TMP/hits.txt ]; then
     echo "check_packed_opsel: $(wc -l < $TMP/hits.txt) packed fp32 instruction(s) with a low lane fed from a high dword in $(basename $co):" >&2
     head -5 $TMP/hits.txt >&2
     n=1
   fi
 done
+# fail closed: a library without a single gfx950 code object was not checked at all
+[ "$objects" -gt 0 ] || { echo "check_packed_opsel: no gfx950 code object found in $LIB -- nothing was checked" >&2; exit 2; }
 exit $n
