@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NFOPP_ABI_VERSION 5
+#define NFOPP_ABI_VERSION 6
 #define NFOPP_HIDDEN 100 /* width of both hidden layers, nfop/onf_model.py:18-23 */
 
 typedef enum nfopp_status {
@@ -128,6 +128,48 @@ int nfopp_traj_update(const nfopp_traj_hyper* hp, int64_t batch, int32_t n_waypo
 int nfopp_reparametrize(int64_t batch, int32_t n_waypoints, int32_t dim, float* traj_dev,
                         const float* start_dev, const float* goal_dev, float* lam_dev, float* cm_dev,
                         const float* u_dev, const uint8_t* active_dev, void* stream);
+
+/* n planner steps of a FROZEN-field batch from one call (ABI 6): the step loops that drive the reference's hot path --
+ * nfop/ros/goal_planner_adapter.py:50-52 (`while time < timeout: planner.step()`), scripts/run_planner.py:76-77,
+ * scripts/run_bench_mr.py:109-132 -- without a host round trip per step.  Per step k = 0 .. n_steps-1, on `stream`:
+ *   nfopp_traj_collision_eval (draws: t_mode 1 = Philox word rng_offset + k; t_mode 0 = row k of t_steps_dev [n_steps, B, N-1])
+ *   nfopp_traj_update with the Adam scalars of step adam_steps_done + k + 1, formed here in double as torch.optim.Adam forms
+ *     them (step_size = lr / (1 - beta1^k), bc2_sqrt = sqrt(1 - beta2^k); hp's two fields are ignored)
+ *   nfopp_reparametrize when (step_count + k) % reparam_freq == 0           (nfop/nerf_opt_planner.py:60-71)
+ * Same kernels and arguments as n single-step sequences: results are bit-identical to them.  terms_dev [B, 8] (or NULL)
+ * receives the loss terms of the LAST step.  The caller advances its own counters by n_steps afterwards.  Nothing
+ * synchronises.  Not for steps with ONF learning: the reference's fit needs the host checker between steps. */
+typedef struct nfopp_traj_buffers {
+  float* traj_dev;             /* [B, N, D] */
+  const float* start_dev;      /* [B, D] */
+  const float* goal_dev;       /* [B, D] */
+  float* lam_dev;              /* [B, N+1], NULL for D = 2 */
+  float* cm_dev;               /* [B, N],   NULL for D = 2 */
+  float* adam_m_dev;           /* [B, N, D] */
+  float* adam_v_dev;           /* [B, N, D] */
+  float* t_dev;                /* [B, N-1] scratch for t_mode 1 (may be NULL for t_mode 0) */
+  float* onf_out4_dev;         /* [B, N-1, 4] scratch */
+  const float* hinv_band_dev;  /* [2*half_width+1, N] */
+  const float* u_dev;          /* [N] = torch.linspace(0, 1, N+2)[1:-1] */
+  const uint8_t* active_dev;   /* [B] or NULL */
+  int32_t* live_ws_dev;        /* [B+1], required with active_dev */
+  int64_t batch;
+  int32_t n_waypoints, dim, half_width, interior_lo, interior_hi;
+} nfopp_traj_buffers;
+
+typedef struct nfopp_step_schedule {
+  double adam_lr, adam_beta1, adam_beta2; /* the trajectory optimiser's Adam group (eps, 1-beta in nfopp_traj_hyper) */
+  int64_t adam_steps_done;                /* Adam steps taken before this call */
+  int64_t step_count;                     /* planner step counter before this call (reparametrisation schedule) */
+  int64_t traj_index_offset;              /* global index of trajectory 0 (Philox counter) */
+  uint64_t seed, rng_offset;              /* t_mode 1: Philox key, word of the first step */
+  int32_t reparam_freq;                   /* >= 1 */
+  int32_t t_mode;                         /* 0 = injected draws (t_steps_dev), 1 = in-kernel Philox */
+} nfopp_step_schedule;
+
+int nfopp_traj_steps(const nfopp_onf_config* cfg, const float* params_dev, const nfopp_traj_hyper* hp,
+                     const nfopp_traj_buffers* buf, const nfopp_step_schedule* sched, int32_t n_steps,
+                     const float* t_steps_dev, float* terms_dev, void* stream);
 
 /* ONF fitting step, gradient part: BCE-with-logits (mean over ALL samples of the job) and its gradient w.r.t.
  * every parameter incl. the angle frequencies (nfop/nerf_opt_planner.py:83-89).

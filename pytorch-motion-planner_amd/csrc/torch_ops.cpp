@@ -148,6 +148,76 @@ void traj_step(const Tensor& params, double mean, double sigma, bool use_cos, bo
                                  opt_ptr<float>(terms), opt_ptr<uint8_t>(active), st));
 }
 
+// n frozen-field planner steps from one call (nfopp_traj_steps, ABI 6): the callers' step loops
+// (nfop/ros/goal_planner_adapter.py:50-52, scripts/run_planner.py:76-77) without a host round trip per step.
+// t_steps: [n_steps, B, N-1] injected draws (t_mode 0) or None (t_mode 1, in-kernel Philox; `t` is the scratch row).
+void traj_steps(const Tensor& params, double mean, double sigma, bool use_cos, bool has_bias, int64_t angle_dim, Tensor traj,
+                const Tensor& start, const Tensor& goal, const OptTensor& lam, const OptTensor& cm, Tensor adam_m, Tensor adam_v,
+                Tensor t, const OptTensor& t_steps, int64_t seed, int64_t rng_offset, int64_t traj_index_offset, Tensor onf_out,
+                const Tensor& hinv_band, int64_t half_width, int64_t interior_lo, int64_t interior_hi, const Tensor& u,
+                at::ArrayRef<double> hyper, double adam_lr, double adam_beta1, double adam_beta2, int64_t adam_steps_done,
+                int64_t step_count, int64_t reparam_freq, int64_t n_steps, const OptTensor& terms, const OptTensor& active,
+                const OptTensor& live_ws) {
+  const nfopp_onf_config c = make_cfg(mean, sigma, use_cos, has_bias, angle_dim);
+  check_params(params, c);
+  check_tensor(traj, "traj");
+  TORCH_CHECK(traj.dim() == 3, "nfopp: traj must be [B, N, D]");
+  const int64_t B = traj.size(0), N = traj.size(1), D = traj.size(2);
+  TORCH_CHECK(D == (angle_dim > 0 ? 3 : 2), "nfopp: trajectory dim ", D, " does not match the ONF point dim");
+  TORCH_CHECK(N >= 2, "nfopp: need at least 2 waypoints");
+  TORCH_CHECK(n_steps >= 0 && reparam_freq >= 1 && adam_steps_done >= 0 && step_count >= 0, "nfopp: bad step schedule");
+  auto need = [&](const Tensor& x, const char* name, at::IntArrayRef shape) {
+    check_tensor(x, name);
+    same_device(traj, x, name);
+    TORCH_CHECK(x.sizes() == shape, "nfopp: ", name, " must have shape ", shape, ", got ", x.sizes());
+  };
+  same_device(traj, params, "params");
+  need(start, "start", {B, D}); need(goal, "goal", {B, D});
+  need(adam_m, "adam_m", {B, N, D}); need(adam_v, "adam_v", {B, N, D});
+  need(t, "t", {B, N - 1}); need(onf_out, "onf_out", {B, N - 1, 4}); need(u, "u", {N});
+  check_tensor(hinv_band, "hinv_band");
+  same_device(traj, hinv_band, "hinv_band");
+  TORCH_CHECK(hinv_band.dim() == 2 && hinv_band.size(0) == 2 * half_width + 1 && hinv_band.size(1) == N,
+              "nfopp: hinv_band must be [2 * half_width + 1, N]");
+  if (D == 3) {
+    TORCH_CHECK(lam.has_value() && cm.has_value(), "nfopp: the SE(2) step needs the multiplier tensors lam [B, N+1], cm [B, N]");
+    need(*lam, "lam", {B, N + 1}); need(*cm, "cm", {B, N});
+  } else {
+    TORCH_CHECK(!lam.has_value() && !cm.has_value(), "nfopp: the 2-D step takes no multiplier tensors (lam / cm must be None)");
+  }
+  if (t_steps.has_value()) need(*t_steps, "t_steps", {n_steps, B, N - 1});
+  if (terms.has_value()) need(*terms, "terms", {B, NFOPP_NUM_TERMS});
+  if (active.has_value()) {
+    check_tensor(*active, "active", at::kByte);
+    same_device(traj, *active, "active");
+    TORCH_CHECK(active->numel() == B, "nfopp: active must be [B] uint8");
+    TORCH_CHECK(live_ws.has_value(), "nfopp: an active mask needs the live-list workspace (B + 1 int32)");
+    check_tensor(*live_ws, "live_ws", at::kInt);
+    same_device(traj, *live_ws, "live_ws");
+    TORCH_CHECK(live_ws->numel() >= B + 1, "nfopp: live_ws must hold B + 1 int32");
+  } else {
+    TORCH_CHECK(!live_ws.has_value(), "nfopp: live_ws without an active mask");
+  }
+  const nfopp_traj_hyper hp = make_hyper(hyper);
+  nfopp_traj_buffers buf;
+  buf.traj_dev = traj.data_ptr<float>(); buf.start_dev = start.data_ptr<float>(); buf.goal_dev = goal.data_ptr<float>();
+  buf.lam_dev = opt_ptr<float>(lam); buf.cm_dev = opt_ptr<float>(cm);
+  buf.adam_m_dev = adam_m.data_ptr<float>(); buf.adam_v_dev = adam_v.data_ptr<float>();
+  buf.t_dev = t.data_ptr<float>(); buf.onf_out4_dev = onf_out.data_ptr<float>();
+  buf.hinv_band_dev = hinv_band.data_ptr<float>(); buf.u_dev = u.data_ptr<float>();
+  buf.active_dev = opt_ptr<uint8_t>(active); buf.live_ws_dev = opt_ptr<int32_t>(live_ws);
+  buf.batch = B; buf.n_waypoints = (int32_t)N; buf.dim = (int32_t)D; buf.half_width = (int32_t)half_width;
+  buf.interior_lo = (int32_t)interior_lo; buf.interior_hi = (int32_t)interior_hi;
+  nfopp_step_schedule sc;
+  sc.adam_lr = adam_lr; sc.adam_beta1 = adam_beta1; sc.adam_beta2 = adam_beta2;
+  sc.adam_steps_done = adam_steps_done; sc.step_count = step_count; sc.traj_index_offset = traj_index_offset;
+  sc.seed = (uint64_t)seed; sc.rng_offset = (uint64_t)rng_offset; sc.reparam_freq = (int32_t)reparam_freq;
+  sc.t_mode = t_steps.has_value() ? 0 : 1;
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(traj.device());
+  check_status(nfopp_traj_steps(&c, params.data_ptr<float>(), &hp, &buf, &sc, (int32_t)n_steps, opt_ptr<float>(t_steps),
+                                opt_ptr<float>(terms), stream_of(traj)));
+}
+
 // arc-length reparametrisation (constrained:132-171 / nerf:224-244), in place
 void reparametrize(Tensor traj, const Tensor& start, const Tensor& goal, const OptTensor& lam, const OptTensor& cm,
                    const Tensor& u, const OptTensor& active) {
@@ -232,6 +302,12 @@ TORCH_LIBRARY(nfopp, lib) {
       "Tensor goal, Tensor(b!)? lam, Tensor(c!)? cm, Tensor(d!) adam_m, Tensor(e!) adam_v, Tensor(f!) t, int t_mode, int seed, "
       "int rng_offset, int traj_index_offset, Tensor(g!) onf_out, Tensor hinv_band, int half_width, int interior_lo, int interior_hi, "
       "float[] hyper, Tensor(h!)? terms, Tensor? active, Tensor(i!)? live_ws) -> ()");
+  lib.def(
+      "traj_steps(Tensor params, float mean, float sigma, bool use_cos, bool has_bias, int angle_dim, Tensor(a!) traj, Tensor start, "
+      "Tensor goal, Tensor(b!)? lam, Tensor(c!)? cm, Tensor(d!) adam_m, Tensor(e!) adam_v, Tensor(f!) t, Tensor? t_steps, int seed, "
+      "int rng_offset, int traj_index_offset, Tensor(g!) onf_out, Tensor hinv_band, int half_width, int interior_lo, int interior_hi, "
+      "Tensor u, float[] hyper, float adam_lr, float adam_beta1, float adam_beta2, int adam_steps_done, int step_count, "
+      "int reparam_freq, int n_steps, Tensor(h!)? terms, Tensor? active, Tensor(i!)? live_ws) -> ()");
   lib.def("reparametrize(Tensor(a!) traj, Tensor start, Tensor goal, Tensor(b!)? lam, Tensor(c!)? cm, Tensor u, Tensor? active) -> ()");
   lib.def("onf_train_grad(Tensor params, Tensor samples, Tensor labels, float inv_count, float mean, float sigma, bool use_cos, "
           "bool has_bias, int angle_dim) -> Tensor");
@@ -248,6 +324,7 @@ TORCH_LIBRARY_IMPL(nfopp, CompositeExplicitAutograd, lib) {
   lib.impl("onf_fwd_bwd_input", &onf_fwd_bwd_input);
   lib.impl("onf_logits", &onf_logits);
   lib.impl("traj_step", &traj_step);
+  lib.impl("traj_steps", &traj_steps);
   lib.impl("reparametrize", &reparametrize);
   lib.impl("onf_train_grad", &onf_train_grad);
   lib.impl("adam_step", &adam_step);
