@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnfopp_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 NUM_TERMS = 8
 TERM_NAMES = ("total", "distance", "softplus_sum", "lambda_dot_c", "c_squared", "boundary", "cm_tanh", "direction")
 
@@ -35,6 +35,25 @@ class TrajHyperC(ctypes.Structure):
 
 
 _P = ctypes.c_void_p
+
+
+class TrajBuffersC(ctypes.Structure):
+    """nfopp_traj_buffers (include/nfopp_hip.h): the device state of one batch, borrowed for nfopp_traj_steps."""
+    _fields_ = [("traj_dev", _P), ("start_dev", _P), ("goal_dev", _P), ("lam_dev", _P), ("cm_dev", _P), ("adam_m_dev", _P),
+                ("adam_v_dev", _P), ("t_dev", _P), ("onf_out4_dev", _P), ("hinv_band_dev", _P), ("u_dev", _P),
+                ("active_dev", _P), ("live_ws_dev", _P), ("batch", ctypes.c_int64), ("n_waypoints", ctypes.c_int32),
+                ("dim", ctypes.c_int32), ("half_width", ctypes.c_int32), ("interior_lo", ctypes.c_int32),
+                ("interior_hi", ctypes.c_int32)]
+
+
+class StepScheduleC(ctypes.Structure):
+    """nfopp_step_schedule: Adam group + counters + draw stream of an n-step call."""
+    _fields_ = [("adam_lr", ctypes.c_double), ("adam_beta1", ctypes.c_double), ("adam_beta2", ctypes.c_double),
+                ("adam_steps_done", ctypes.c_int64), ("step_count", ctypes.c_int64), ("traj_index_offset", ctypes.c_int64),
+                ("seed", ctypes.c_uint64), ("rng_offset", ctypes.c_uint64), ("reparam_freq", ctypes.c_int32),
+                ("t_mode", ctypes.c_int32)]
+
+
 _SIGNATURES = {
     "nfopp_abi_version": (ctypes.c_int, []),
     "nfopp_last_error": (ctypes.c_char_p, []),
@@ -48,6 +67,8 @@ _SIGNATURES = {
     "nfopp_traj_update": (ctypes.c_int, [ctypes.POINTER(TrajHyperC), ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int32, _P, _P, _P]),
+    "nfopp_traj_steps": (ctypes.c_int, [ctypes.POINTER(OnfConfigC), _P, ctypes.POINTER(TrajHyperC), ctypes.POINTER(TrajBuffersC),
+                                        ctypes.POINTER(StepScheduleC), ctypes.c_int32, _P, _P, _P]),
     "nfopp_reparametrize": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nfopp_path_interpolate": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                               _P, _P, _P]),

@@ -194,7 +194,23 @@ class BatchPlanner(object):
         gb = self.global_batch if self.global_batch is not None else self.fitter.world_size() * eng.B
         return self.fitter.step(samples, labels, global_count=gb * self.sampler.S)
 
-    def step(self, t=None, want_terms=False):
+    def step(self, t=None, want_terms=False, n=1):
+        """One planner step for the whole batch -- or `n` of them (`step(n=...)`): with a frozen field (no checker) the n
+        steps are enqueued by ONE library call (nfopp_traj_steps), without returning to Python in between -- the form
+        the callers' loops want (nfop/ros/goal_planner_adapter.py:50-52, scripts/run_planner.py:76-77).  With continuous
+        learning every fit needs fresh samples, so the steps run one by one.  `t` [B, N-1] (n = 1) or [n, B, N-1]
+        injects the draws.  Bit-identical to n calls of `step()`."""
+        n = int(n)
+        if n > 1 or (n == 1 and self.checker is None and t is None):
+            if self.checker is None:
+                self.engine.steps(n, self.step_count, self.reparam_freq, t_steps=t, want_terms=want_terms)
+                self.step_count += n
+                return
+            for k in range(n):
+                self.step(None if t is None else t[k], want_terms=want_terms and k == n - 1)
+            return
+        if n < 1:
+            return
         if self.checker is not None and self.step_count % self.fit_freq == 0:
             self.fit_field()
         self.engine.optimize_trajectory(t, want_terms=want_terms)

@@ -190,6 +190,40 @@ class TrajectoryEngine(object):
         self.collision_eval(t)
         self.update(want_terms)
 
+    def steps(self, n, step_count, reparam_freq, t_steps=None, want_terms=False):
+        """`n` frozen-field planner steps enqueued by ONE library call (nfopp_traj_steps, ABI 6): per step
+        collision_eval -> update -> reparametrize when (step_count + k) % reparam_freq == 0, with each step's Adam scalars
+        formed on the C side as `TrajectoryHyper.to_c` forms them.  Bit-identical to n single steps.  `t_steps`
+        [n, B, N-1] injects the draws (parity mode), None = in-kernel Philox (word rng_offset + k).  The ONF must not
+        change during the call; nothing synchronises."""
+        n = int(n)
+        if n <= 0:
+            return
+        lib = _lib.load()
+        cfg = self.onf.config_c()
+        hp = self.hyper.to_c(self.adam_step + 1)
+        if self.active is not None and self._live is None:
+            self._live = torch.zeros(self.B + 1, dtype=torch.int32, device=self.device)
+        P = _lib.ptr
+        buf = _lib.TrajBuffersC(P(self.traj), P(self.start), P(self.goal), P(self.lam), P(self.cm), P(self.adam_m),
+                                P(self.adam_v), P(self.t), P(self.onf_out), P(self.hinv_band), P(self.u),
+                                P(self.active, torch.uint8), P(self._live, torch.int32) if self.active is not None else None,
+                                self.B, self.N, self.D, self.half_width, self.interior[0], self.interior[1])
+        tdev = None
+        if t_steps is not None:
+            tdev = torch.as_tensor(t_steps, dtype=torch.float32).reshape(n, self.B, self.N - 1).to(self.device).contiguous()
+        b1, b2 = self.hyper.betas
+        sched = _lib.StepScheduleC(float(self.hyper.lr), float(b1), float(b2), self.adam_step, int(step_count),
+                                   self.traj_index_offset, self.seed, self.rng_offset, int(reparam_freq),
+                                   0 if tdev is not None else 1)
+        _lib.check(lib.nfopp_traj_steps(cfg, P(self.onf.flat_parameters), hp, buf, sched, n, P(tdev),
+                                        P(self.terms) if want_terms else None, _lib.stream_ptr()))
+        self.adam_step += n
+        if tdev is None:
+            self.rng_offset += n
+        else:
+            self._t_steps_keepalive = tdev   # the kernels read it asynchronously; the last step's row is also K2's `t`
+
     def reparametrize(self):
         lib = _lib.load()
         _lib.check(lib.nfopp_reparametrize(self.B, self.N, self.D, _lib.ptr(self.traj), _lib.ptr(self.start),

@@ -125,13 +125,33 @@ class NERFOptPlanner(ContinuousPlanner):
         return self._engine.goal
 
     # ---- step ---------------------------------------------------------------------------------------------------------
-    def step(self):
-        if self._step_count % self._optimize_collision_model_freq == 0:
-            self._optimize_collision_model()
-        self._optimize_trajectory()
-        if self._step_count % self._reparametrize_trajectory_freq == 0:
-            self.reparametrize_trajectory()
-        self._step_count += 1
+    def step(self, n=1):
+        """The reference's `step()` (nerf:60-71).  `step(n)` runs n of them; the stretches between two ONF fitting steps
+        (all n when `optimize_collision_model_freq` exceeds the horizon, i.e. a frozen field) are enqueued by ONE library
+        call each (nfopp_traj_steps) instead of a Python round trip per step -- what a budgeted caller loop wants
+        (nfop/ros/goal_planner_adapter.py:50-52: `while time < timeout: planner.step()` becomes `planner.step(chunk)`).
+        Results are bit-identical to n single calls: the per-step draws are taken from the same generator in the same
+        order.  On return the steps are enqueued; `get_path()` synchronises, as before."""
+        n = int(n)
+        while n > 0:
+            freq = self._optimize_collision_model_freq
+            if self._step_count % freq == 0:
+                self._optimize_collision_model()
+            run = min(n, freq - self._step_count % freq)      # steps until the next fit falls due
+            if run > 1:
+                self._sync_hyper()
+                draws = [self._draw_t() for _ in range(run)]
+                t_steps = None if draws[0] is None else torch.stack([d.reshape(-1) for d in draws])[:, None, :]
+                with self._collision_model.frozen():           # the field cannot change inside the run
+                    self._engine.steps(run, self._step_count, self._reparametrize_trajectory_freq, t_steps=t_steps,
+                                       want_terms=True)
+                self._step_count += run
+            else:
+                self._optimize_trajectory()
+                if self._step_count % self._reparametrize_trajectory_freq == 0:
+                    self.reparametrize_trajectory()
+                self._step_count += 1
+            n -= run
 
     def full_trajectory(self):
         return self._engine.full_trajectory()[0]

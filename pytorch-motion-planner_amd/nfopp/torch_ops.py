@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 TORCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnfopp_torch.so")
-OPS = ("onf_fwd_bwd_input", "onf_logits", "traj_step", "reparametrize", "onf_train_grad", "adam_step", "onf_train_step")
+OPS = ("onf_fwd_bwd_input", "onf_logits", "traj_step", "traj_steps", "reparametrize", "onf_train_grad", "adam_step", "onf_train_step")
 _loaded = False
 
 

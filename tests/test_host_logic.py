@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_header_symbol():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nfopp_abi_version() == 5
+    assert lib.nfopp_abi_version() == 6
     assert lib.nfopp_device_count() >= 0
 
 
@@ -51,6 +51,9 @@ def test_struct_layouts_match_header():
     import ctypes
     assert ctypes.sizeof(_lib.OnfConfigC) == 20
     assert ctypes.sizeof(_lib.TrajHyperC) == 4 * (8 + 4 + 6)
+    # nfopp_traj_buffers: 13 pointers, int64, 5 int32 (+4 tail padding); nfopp_step_schedule: 3 doubles, 3 int64, 2 uint64, 2 int32
+    assert ctypes.sizeof(_lib.TrajBuffersC) == 13 * 8 + 8 + 5 * 4 + 4
+    assert ctypes.sizeof(_lib.StepScheduleC) == 3 * 8 + 3 * 8 + 2 * 8 + 2 * 4
 
 
 def test_param_count_and_argument_errors_without_gpu():

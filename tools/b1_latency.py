@@ -1,4 +1,5 @@
-"""Dev measurement: wall time per `.step()` of the B=1 drop-in planner (BASELINE configs[1]: 1 x 256, ONF learning on)."""
+"""Dev measurement: wall time per planner step of the B=1 drop-in planner (BASELINE configs[1]: 1 x 256) -- one `.step()` per
+Python call vs `step(n)` (n steps enqueued by one library call, nfopp_traj_steps) -- and of a small BatchPlanner."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,16 +8,39 @@ for p in (ROOT, os.path.join(ROOT, "pytorch-motion-planner_amd"), os.path.join(R
 import nfopp
 from test_gpu_planner_api import _params
 z = np.load(os.path.join(ROOT, "tests/golden/g9_full_steps.npz"))
-for freeze in (False, True):
+
+
+def make(freeze):
     torch.random.manual_seed(100); np.random.seed(400)
     cc = nfopp.CircleDirectedCollisionChecker(0.3, (0, 3, 0, 3)); cc.update_obstacle_points(z["obstacles"]); cc.update_boundaries(tuple(z["bounds"]))
     pl = nfopp.PlannerFactory.make_constrained_onf_planner(cc, _params(256))
     pl.init(z["start"], z["goal"], tuple(z["bounds"]))
     if freeze:
         pl._optimize_collision_model_freq = 10 ** 9; pl._step_count = 1
+    return pl
+
+
+K = 300
+for freeze, chunk in ((False, 1), (True, 1), (True, 10), (True, 50), (True, 300)):
+    pl = make(freeze)
     for _ in range(30): pl.step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    K = 300
-    for _ in range(K): pl.step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-    print("B=1 N=256 %s: %.3f ms/step  (%.0f steps/s, %.3g waypoint-evals/s)" % ("frozen ONF" if freeze else "ONF learning on", dt * 1e3, 1 / dt, 256 / dt))
+    for _ in range(K // chunk): pl.step(chunk) if chunk > 1 else pl.step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (K // chunk * chunk)
+    print("B=1 N=256 %-15s step(%3d): %.1f us/step  (%.0f steps/s)" % ("frozen ONF" if freeze else "ONF learning on", chunk, dt * 1e6, 1 / dt))
+    if freeze and chunk == 300:   # device time alone: events around one chunk
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); pl.step(300); e1.record(); torch.cuda.synchronize()
+        print("   device time of step(300) between events: %.1f us/step" % (e0.elapsed_time(e1) * 1e3 / 300))
+pl = make(True)
+pl._rng = "device"
+for _ in range(30): pl.step()
+torch.cuda.synchronize(); t0 = time.perf_counter(); pl.step(300); torch.cuda.synchronize()
+print("B=1 N=256 frozen, device Philox draws, step(300): %.1f us/step" % ((time.perf_counter() - t0) / 300 * 1e6))
+for B in (1, 16, 64):
+    onf = pl._collision_model
+    bp = nfopp.BatchPlanner(onf, B, 256, pl._make_hyper(), device="cuda", seed=1)
+    st = np.repeat(z["start"][None], B, 0); go = np.repeat(z["goal"][None], B, 0)
+    bp.init(st, go, tuple(z["bounds"]))
+    bp.step(n=50); torch.cuda.synchronize(); t0 = time.perf_counter(); bp.step(n=300); torch.cuda.synchronize()
+    print("BatchPlanner B=%d N=256 frozen step(n=300): %.1f us/step" % (B, (time.perf_counter() - t0) / 300 * 1e6))
