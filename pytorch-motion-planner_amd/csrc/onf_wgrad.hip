@@ -129,6 +129,15 @@ __device__ __forceinline__ f32x4 features4_scalar(const f32x4& wx, const f32x4& 
   return v;
 }
 
+// the same for four POSITIONAL features (sin / cos of the encoding layer): no angle argument, no select -- the values of
+// features4_scalar for isa == 0, bit for bit
+__device__ __forceinline__ f32x4 features4_positional(const f32x4& wx, const f32x4& wy, const f32x4& b, const f32x4& qh, float ux, float uy) {
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = sin_halfturns_hw(fmaf(wx[k], ux, fmaf(wy[k], uy, b[k])), qh[k]);
+  return v;
+}
+
 template <int NKT>
 __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArgs a) {
   using W = WgLayout<NKT>;
@@ -432,11 +441,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// Wait states behind a group of MFMAs before its fragment registers are reloaded.  A precaution, not a proven need: the
-// run-to-run differences it was written against turned out to come from a packed fma with op_sel on freshly loaded LDS values
-// ("A hazard hipcc does not pad"); it costs nothing here because the multiplying waves wait at the barriers anyway.
+// Wait states behind a group of MFMAs before its fragment registers are reloaded (make EXTRA=-DNFOPP_MFMA_GUARD).  A precaution of
+// round 2 against run-to-run differences that turned out to come from a packed fma with op_sel on freshly loaded LDS values
+// (DESIGN.md K5); hipcc's hazard recogniser handles MFMA operand reuse for builtins.
 __device__ __forceinline__ void mfma_guard() {
-#ifndef NFOPP_NO_MFMA_GUARD
+#ifdef NFOPP_MFMA_GUARD   /* round 4: OFF by default -- 24 guards x 64 wait states per chunk were 13 % of the kernel once the
+                             multiplying waves had become its critical path; the bit-for-bit repeat tests pass without them */
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");   // 64 wait states: four MFMA issue slots
   __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -537,9 +547,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     // item = one float4 of one sample of the chunk; array with row4 float4 per sample: idx = pt + j * 256 -> (q, c).
     // Surplus threads repeat the last item (same data, same place: no branches in the staging code).
     constexpr int N_H = (KS * H4 + PT - 1) / PT, N_W = (KS * W4 + PT - 1) / PT;
-    // two register sets per array: the loads of chunk k+1 are issued at the START of the phase that commits chunk k (a whole
-    // chunk time ahead of their use, and spread over the phase instead of one burst per workgroup at its end)
-    f32x4 st_dh1[2][N_H], st_h1[2][N_H], st_de[2][N_W], st_rec[2];
+    // ONE register set per array: a chunk's rows are committed at the start of their phase and the same registers are re-loaded
+    // with the next chunk's rows right behind the commit -- a whole chunk time ahead of their use.  (Round 3 kept two sets and
+    // issued the loads in front of the commit; with the feature registers below that no longer fits 256 registers.)
+    f32x4 st_dh1[N_H], st_h1[N_H], st_de[N_W], st_rec;
     int hqc[N_H], wqc[N_W];   // sample q << 8 | float4 c
 #pragma unroll
     for (int j = 0; j < N_H; ++j) {
@@ -575,7 +586,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       for (int j = 0; j < N_H; ++j) {
         int q, c;
         unpack(hqc[j], q, c);
+#ifdef NFOPP_ABL2_NO_LOAD   /* development ablation (timing only): no HBM traffic, the arithmetic and LDS work stay */
+        st[j] = f32x4{(float)q, (float)c, 1.0f + (float)chunk, 2.0f};
+        asm volatile("" : "+v"(st[j]));
+#else
         st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (HS * 4) + 16 * c, 0, 0));
+#endif
       }
     };
     auto load_de = [&](f32x4 (&st)[N_W], long long chunk) __attribute__((always_inline)) {
@@ -584,12 +600,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       for (int j = 0; j < N_W; ++j) {
         int q, c;
         unpack(wqc[j], q, c);
+#ifdef NFOPP_ABL2_NO_LOAD
+        st[j] = f32x4{(float)q, (float)c, 1.0f + (float)chunk, 2.0f};
+        asm volatile("" : "+v"(st[j]));
+#else
         st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * (WIN * 4) + 16 * c, 0, 0));
+#endif
       }
     };
     auto load_rec = [&](f32x4& st, long long chunk) __attribute__((always_inline)) {
       const auto rsrc = chunk_rsrc(ws_rec, chunk, 12);
+#ifdef NFOPP_ABL2_NO_LOAD
+      st = f32x4{0.25f, 0.5f, 1.0f, 0.1f * (float)(chunk & 7)};
+      asm volatile("" : "+v"(st));
+#else
       st = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rq * 48 + 16 * rc, 0, 0));
+#endif
     };
     // XO: dh2 = rho * [a2 > 0] takes only the values rho and 0, so rho is split ONCE per sample, here: the record's unused
     // words 5..7 carry its three levels, each in both halves of the word, and a dh2 pair is a level word ANDed with a mask
@@ -610,7 +636,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       for (int j = 0; j < N_H; ++j) {
         int q, c;
         unpack(hqc[j], q, c);
+#ifdef NFOPP_ABL2_NO_SPLIT_H   /* development ablation (timing only): h1 / dh1 committed without the split arithmetic */
+        const u32x2 raw{__float_as_uint(st[j].x), __float_as_uint(st[j].z)};
+        *reinterpret_cast<u32x2*>(lds + img + q * L::R_H + 2 * c) = raw;
+        *reinterpret_cast<u32x2*>(lds + img + L::P_H + q * L::R_H + 2 * c) = raw;
+        *reinterpret_cast<u32x2*>(lds + img + 2 * L::P_H + q * L::R_H + 2 * c) = u32x2{__float_as_uint(st[j].y), __float_as_uint(st[j].w)};
+#else
         store_split4(lds, img, L::P_H, q * L::R_H + 2 * c, st[j]);
+#endif
       }
     };
     // Rebuilt operands.  A thread's items keep their columns from chunk to chunk, so the table entries they need sit in
@@ -621,7 +654,17 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     for (int j = 0; j < N_H; ++j) w3a_reg[j] = *reinterpret_cast<const f32x4*>(lds + L::L_W3A + 4 * (hqc[j] & 255));
     constexpr int SP = PT / W4, T_I = SP * W4, N_I = (KS + SP - 1) / SP;
     const int it_in = pt < T_I ? pt : pt - T_I;       // surplus threads repeat other owners' work
-    const int in_s4 = it_in % W4, in_q0 = it_in / W4;
+    // x32 order (slots = feature indices): the positional quads are dealt to the first threads, the quads that can hold angle /
+    // ones / pad slots to the last ones, so that whole WAVES evaluate positional features only and skip the angle argument and
+    // the select (4 of 14 instructions per feature; the evaluation is 40 % of the staging waves' work)
+    constexpr int NPQ = XO ? (NKT >= 13 ? 50 : 25) : 0, NSQ = W4 - NPQ;   // encoding-layer features / 4 (200 or 100 of them)
+    const int in_s4 = !XO ? it_in % W4 : (it_in < NPQ * SP ? it_in % NPQ : NPQ + (it_in - NPQ * SP) % NSQ);
+    const int in_q0 = !XO ? it_in / W4 : (it_in < NPQ * SP ? it_in / NPQ : (it_in - NPQ * SP) / NSQ);
+#ifdef NFOPP_ABL2_GENERIC_FEATURES   /* development A/B: every wave on the general evaluation */
+    const bool pos_only = false;
+#else
+    const bool pos_only = XO && (wave - WG_WAVES / 2) * 64 + 63 < NPQ * SP;   // wave-uniform
+#endif
     f32x4 t_wx, t_wy, t_b, t_fr, t_qh, t_isa;
     {
       const float* e = lds + L::L_FT + 4 * in_s4;
@@ -633,24 +676,52 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     float wg_ticks[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned long long wg_t0 = __builtin_readcyclecounter();
 #endif
-    // phase A(k)'s staging (register set s = record area of chunk k), into bufB: h1, de, u, dh2 of chunk k; the record of chunk
-    // k+1 -> area s^1.  Loads first: h1, de of chunk k+1 and the record of chunk k+2 into the other set.
+    // The input features of chunk k+1 are EVALUATED in phase A(k) -- into registers, from the record committed one phase
+    // earlier -- and only split and stored in phase B(k).  (Round 3 evaluated and stored them in phase B: in-kernel stamps showed
+    // phase A bound by the multiplying waves' G1 (6.8 k cycles, the staging waves idle for 2.5 k of them) and phase B by this
+    // evaluation (4.8 k of 6.0 k, the multiplying waves idle for 3 k).  Same arithmetic, same values: bit-identical results.)
+    f32x4 feat[N_I];
+    auto eval_in = [&](const float* rec) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < N_I; ++j) {
+        int q = in_q0 + SP * j;   // in slots 4 s4 .. 4 s4 + 3 of sample q = features(u), pass 1's arithmetic
+        q = q < KS ? q : KS - 1;
+        const float ux = rec[q * 12], uy = rec[q * 12 + 1], th = rec[q * 12 + 3];
+#ifdef NFOPP_ABL2_NO_IN   /* development ablation (timing only): no feature evaluation, the split and the stores stay */
+        feat[j] = f32x4{ux + t_wx.x, uy + t_wx.y, th + t_wx.z, ux + t_wx.w};
+#else
+        feat[j] = pos_only ? features4_positional(t_wx, t_wy, t_b, t_qh, ux, uy)
+                           : features4_scalar(t_wx, t_wy, t_b, t_fr, t_qh, t_isa, ux, uy, th);
+#endif
+        // pinned: without this LLVM sinks the (pure) evaluation to its use behind the phase barrier, i.e. back into phase B
+        asm volatile("" : "+v"(feat[j]));
+      }
+    };
+    auto store_in = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < N_I; ++j) {
+        int q = in_q0 + SP * j;
+        q = q < KS ? q : KS - 1;
+        store_split4(lds, L::A_IN, L::P_IN, q * L::R_IN + 2 * in_s4, feat[j]);
+      }
+    };
+    // phase A(k)'s staging (register set s = record area of chunk k), into bufB: h1, de, u, dh2 of chunk k; then the features of
+    // chunk k+1 from record area s^1 (committed in phase B(k-1)) into registers.  Loads first: h1, de of chunk k+1 into the other
+    // set and the record of chunk k+2 (committed in phase B(k)).
     auto stage_b = [&](auto set_c, long long chunk) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
-      load_h(ws_h1, st_h1[S ^ 1], chunk + step);
-      load_de(st_de[S ^ 1], chunk + step);
-      load_rec(st_rec[S ^ 1], chunk + 2 * step);
-      WG_TICK(4)
       const float* rec = lds + L::REC + S * KS * 12;
-      commit_rec(st_rec[S], S ^ 1);
-      commit_h(L::B_H1, st_h1[S]);
+      commit_h(L::B_H1, st_h1);
+      load_h(ws_h1, st_h1, chunk + step);
       WG_TICK(5)
 #pragma unroll
       for (int j = 0; j < N_W; ++j) {
         int q, c;
         unpack(wqc[j], q, c);
-        *reinterpret_cast<f32x4*>(lds + L::B_DE + q * L::RS_DE + 4 * c) = st_de[S][j];
+        *reinterpret_cast<f32x4*>(lds + L::B_DE + q * L::RS_DE + 4 * c) = st_de[j];
       }
+      load_de(st_de, chunk + step);
+      load_rec(st_rec, chunk + 2 * step);
       { const int t = pt & (KS * 4 - 1); lds[L::B_DE + (t >> 2) * L::RS_DE + WIN + (t & 3)] = rec[(t >> 2) * 12 + (t & 3)]; }
       WG_TICK(6)
 #pragma unroll
@@ -676,36 +747,34 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
         for (int r = 0; r < 4; ++r) v[r] = ((bits >> r) & 1u) ? w3a_reg[j][r] * rho : 0.0f;
         store_split4(lds, L::B_DH2, L::P_H, q * L::R_H + 2 * c, v);
       }
+      WG_TICK(7)
+      eval_in(lds + L::REC + (S ^ 1) * KS * 12);
     };
-    // phase B(k)'s staging, into bufA: dh1 (set s) and in = features(u) of chunk k+1 (record area s^1); first the load of
-    // dh1 of chunk k+2 into the other set
+    // phase B(k)'s staging, into bufA: dh1 (set s) and the split features of chunk k+1; the record of chunk k+2 -> area s (last read
+    // in phase A(k)); first the load of dh1 of chunk k+2 into the other set
     auto stage_a = [&](auto set_c, long long chunk) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
-      load_h(ws_dh1, st_dh1[S ^ 1], chunk + 2 * step);
-      WG_TICK(8)
-      const float* rec = lds + L::REC + (S ^ 1) * KS * 12;
-      commit_h(L::A_DH1, st_dh1[S]);
+      commit_rec(st_rec, S);
+      commit_h(L::A_DH1, st_dh1);
+      load_h(ws_dh1, st_dh1, chunk + 2 * step);
       WG_TICK(9)
-#pragma unroll
-      for (int j = 0; j < N_I; ++j) {
-        int q = in_q0 + SP * j;   // in slots 4 s4 .. 4 s4 + 3 of sample q = features(u), pass 1's arithmetic
-        q = q < KS ? q : KS - 1;
-        const float ux = rec[q * 12], uy = rec[q * 12 + 1], th = rec[q * 12 + 3];
-        const f32x4 v = features4_scalar(t_wx, t_wy, t_b, t_fr, t_qh, t_isa, ux, uy, th);
-        store_split4(lds, L::A_IN, L::P_IN, q * L::R_IN + 2 * in_s4, v);
-      }
+      store_in();
     };
-    // prologue: record(c0) -> area 0 and bufA(c0) in place; record(c0 + step), h1 / de (c0) and dh1(c0 + step) in set 0
+    // prologue: record(c0) -> area 0, record(c0 + step) -> area 1, bufA(c0) in place; h1 / de (c0) and dh1(c0 + step) in set 0
     if (c0 < n_chunks) {
-      load_rec(st_rec[1], c0);
-      load_h(ws_dh1, st_dh1[1], c0);
-      load_rec(st_rec[0], c0 + step);           // past P: zeros
-      load_h(ws_h1, st_h1[0], c0);
-      load_de(st_de[0], c0);
-      commit_rec(st_rec[1], 0);
+      f32x4 r0, r1;
+      load_rec(r0, c0);
+      load_h(ws_dh1, st_dh1, c0);
+      load_rec(r1, c0 + step);                  // past P: zeros
+      load_h(ws_h1, st_h1, c0);
+      load_de(st_de, c0);
+      commit_rec(r0, 0);
+      commit_rec(r1, 1);
       phase_barrier();
-      // = stage_a of a chunk "c0 - step" whose set is 1: stages dh1(c0) from set 1 with record area 0, loads dh1(c0 + step) -> set 0
-      stage_a(std::integral_constant<int, 1>{}, c0 - step);
+      commit_h(L::A_DH1, st_dh1);
+      load_h(ws_dh1, st_dh1, c0 + step);
+      eval_in(lds + L::REC);
+      store_in();
       phase_barrier();
     }
     auto one_chunk = [&](auto set_c, long long chunk) __attribute__((always_inline)) {
@@ -724,9 +793,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     }
 #ifdef NFOPP_WG_PROFILE
     if (blockIdx.x == 0 && tid == WG_THREADS / 2)
-      printf("producer wave 4: phase A: loads %.0f, h1 %.0f, de + u %.0f, dh2 %.0f | barrier %.0f | phase B: load %.0f, dh1 %.0f, in %.0f "
-             "| barrier %.0f ticks\n", wg_ticks[4], wg_ticks[5], wg_ticks[6], wg_ticks[0], wg_ticks[1], wg_ticks[8], wg_ticks[9],
-             wg_ticks[2], wg_ticks[3]);
+      printf("producer wave 4: phase A: loads %.0f, h1 %.0f, de + u %.0f, dh2 %.0f, features %.0f | barrier %.0f | phase B: load %.0f, "
+             "rec + dh1 %.0f, in split %.0f | barrier %.0f ticks\n", wg_ticks[4], wg_ticks[5], wg_ticks[6], wg_ticks[7], wg_ticks[0],
+             wg_ticks[1], wg_ticks[8], wg_ticks[9], wg_ticks[2], wg_ticks[3]);
 #endif
     return;
   }
@@ -739,16 +808,30 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
   const int grp = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, i16 = lane & 15;
   const int row0 = 16 * (grp >> 1) + 4 * (grp & 1) + qq;   // lane part of every transposing read: sample row, dwords 2p
   const int lane_h = row0 * L::R_H + 2 * pp, lane_in = row0 * L::R_IN + 2 * pp;
+  constexpr int R_F = L::R_H, LS_F = L::P_H;   // images of h1 / dh1: three planes [KS][R_H]
+  const int lane_f = lane_h;
   const int g2_cb0 = wave < 2 ? wave : 2 * wave - 2, g2_cb1 = wave < 2 ? 6 : 2 * wave - 1;
   // one base register per image, with this wave's first column block folded in: every read offset below is a compile-time
   // constant under 64 KB and goes into the instruction's offset field
-  const float* const bA_dh1 = lds + L::A_DH1 + lane_h;
+  const float* const bA_dh1 = lds + L::A_DH1 + lane_f;
   const float* const bA_in = lds + L::A_IN + lane_in + 8 * wave;          // + 32 dwords per further column block
   const float* const bB_dh2 = lds + L::B_DH2 + lane_h;
-  const float* const bB_h1a = lds + L::B_H1 + lane_h + 8 * g2_cb0;
-  const float* const bB_h1b = lds + L::B_H1 + lane_h + 8 * g2_cb1;
+  const float* const bB_h1a = lds + L::B_H1 + lane_f + 8 * g2_cb0;
+  const float* const bB_h1b = lds + L::B_H1 + lane_f + 8 * g2_cb1;
+#ifdef NFOPP_G3_16X16
   const float* const rowk = lds + L::B_DE + grp * L::RS_DE + i16;
+#endif
   f32x4 acc1[4][7], acc2[2][7], acc3[4];
+  // G3 = de^T u has 4 useful columns (u_x, u_y, 1, theta): on v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4 x 4 blocks, one
+  // rank-1 update each -- a lane feeds de[sample][64 w + lane] and u[sample][lane & 3], every output is a useful one and an
+  // instruction takes 8 pipe cycles; the 16x16x4 form spent 32 cycles on tiles whose 12 other columns are zero, and an fp32 MFMA
+  // blocks the SIMD's vector issue for its whole duration (no co-execution), i.e. the staging partner too.  Wave w owns rows
+  // 64 w .. 64 w + 63; two alternating accumulators (even / odd samples), added at the end in a fixed order.
+  f32x4 acc3e = f32x4{0.f, 0.f, 0.f, 0.f}, acc3o = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int G3_RA = L::RS_DE, G3_RB = L::RS_DE;   // row stride of the  de | u tile  rows
+  const float* const g3_a = lds + L::B_DE + 64 * wave + lane;
+  const float* const g3_b = lds + L::B_DE + WIN + (lane & 3);
+  const bool g3_mine = 64 * wave < WIN;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -761,23 +844,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
   for (int j = 0; j < 4; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // 7 row blocks against one pair of column blocks; the A fragments ping-pong between two register sets (no copies)
-  auto mul_pair = [&](const float* a_base, const float* b0_base, const float* b1_base, int b_plane, auto r_in_c,
+  // (image geometry as compile-time constants: row length and level step of the A image and of the B image)
+  auto mul_pair = [&](const float* a_base, const float* b0_base, const float* b1_base, auto ra_c, auto la_c, auto rb_c, auto lb_c,
                       f32x4 (&c0)[7], f32x4 (&c1)[7]) __attribute__((always_inline)) {
-    constexpr int RB = decltype(r_in_c)::value;   // row length of the B image
+    constexpr int RA = decltype(ra_c)::value, LA = decltype(la_c)::value, RB = decltype(rb_c)::value, LB = decltype(lb_c)::value;
     s16x8 bf0[3], bf1[3], af[2][3];
     mfma_guard();   // the fragment registers below were operands of the MFMAs just issued
 #pragma unroll
     for (int lv = 0; lv < 3; ++lv) {
-      bf0[lv] = read_frag<RB>(b0_base, lv * b_plane);
-      bf1[lv] = read_frag<RB>(b1_base, lv * b_plane);
-      af[0][lv] = read_frag<L::R_H>(a_base, lv * L::P_H);
+      bf0[lv] = read_frag<RB>(b0_base, lv * LB);
+      bf1[lv] = read_frag<RB>(b1_base, lv * LB);
+      af[0][lv] = read_frag<RA>(a_base, lv * LA);
     }
     static_for<0, 7>([&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
       if constexpr (r + 1 < 7) {
         if constexpr (r > 0) mfma_guard();   // set (r + 1) & 1 was read by step r - 1's MFMAs, issued just before
 #pragma unroll
-        for (int lv = 0; lv < 3; ++lv) af[(r + 1) & 1][lv] = read_frag<L::R_H>(a_base, lv * L::P_H + 8 * (r + 1));
+        for (int lv = 0; lv < 3; ++lv) af[(r + 1) & 1][lv] = read_frag<RA>(a_base, lv * LA + 8 * (r + 1));
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma_split_pair(af[r & 1], bf0, bf1, c0[r], c1[r]);
@@ -794,13 +878,29 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
 #endif
   for (long long chunk = c0; chunk < n_chunks; chunk += step) {
     // phase A: G1 out of bufA
-    mul_pair(bA_dh1, bA_in, bA_in + 32, L::P_IN, std::integral_constant<int, L::R_IN>{}, acc1[0], acc1[1]);
-    mul_pair(bA_dh1, bA_in + 64, bA_in + 96, L::P_IN, std::integral_constant<int, L::R_IN>{}, acc1[2], acc1[3]);
+    using ic_rf = std::integral_constant<int, R_F>;
+    using ic_lf = std::integral_constant<int, LS_F>;
+    using ic_rin = std::integral_constant<int, L::R_IN>;
+    using ic_pin = std::integral_constant<int, L::P_IN>;
+    using ic_rh = std::integral_constant<int, L::R_H>;
+    using ic_ph = std::integral_constant<int, L::P_H>;
+    mul_pair(bA_dh1, bA_in, bA_in + 32, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, acc1[0], acc1[1]);
+    mul_pair(bA_dh1, bA_in + 64, bA_in + 96, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, acc1[2], acc1[3]);
     WG_TICK(0)
     phase_barrier();
     WG_TICK(1)
     // phase B: G2 and G3 out of bufB
-    mul_pair(bB_dh2, bB_h1a, bB_h1b, L::P_H, std::integral_constant<int, L::R_H>{}, acc2[0], acc2[1]);
+    mul_pair(bB_dh2, bB_h1a, bB_h1b, ic_rh{}, ic_ph{}, ic_rf{}, ic_lf{}, acc2[0], acc2[1]);
+#if !defined(NFOPP_ABL2_NO_G3) && !defined(NFOPP_G3_16X16)
+    if (g3_mine) {
+#pragma unroll
+      for (int q = 0; q < KS; q += 2) {
+        acc3e = __builtin_amdgcn_mfma_f32_4x4x1f32(g3_a[q * G3_RA], g3_b[q * G3_RB], acc3e, 0, 0, 0);
+        acc3o = __builtin_amdgcn_mfma_f32_4x4x1f32(g3_a[(q + 1) * G3_RA], g3_b[(q + 1) * G3_RB], acc3o, 0, 0, 0);
+      }
+    }
+#endif
+#if !defined(NFOPP_ABL2_NO_G3) && defined(NFOPP_G3_16X16)
 #pragma unroll
     for (int s = 0; s < KS / 4; ++s) {          // G3: four independent fp32 chains, k-step outer
       const float bu = rowk[4 * s * L::RS_DE + WIN];
@@ -810,6 +910,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
         acc3[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rowk[4 * s * L::RS_DE + 16 * rb], bu, acc3[j], 0, 0, 0);
       }
     }
+#endif
     WG_TICK(2)
     phase_barrier();
     WG_TICK(3)
@@ -837,9 +938,33 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     const bool mine = wave >= 2 || (wave == 0 ? r < 4 : r >= 4);   // column block 6 is split by rows between waves 0 and 1
     if (mine) put(7 * NKT + r * 7 + g2_cb1, acc2[1][r]);
   }
+#ifdef NFOPP_G3_16X16
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (wave + 4 * j < NKT) put(7 * NKT + 49 + wave + 4 * j, acc3[j]);
+#else
+  // G3 tiles in the 16 x 16 tile order the reduce / gather kernels read: row k, column c -> tile k / 16, element
+  // 16 ((k % 16) / 4) + c + 64 (k % 4).  This lane holds rows 64 w + 4 (lane / 4) + i, column lane & 3; the columns 4..15 of
+  // the tiles (the zero columns of the 16x16x4 form) are written as zeros by the lanes that own none of the others.
+  {
+    const f32x4 g3 = acc3e + acc3o;
+    const int rb = 4 * wave + (lane >> 4);
+    float* o = a.partial + ((long long)blockIdx.x * L::NTILES + 7 * NKT + 49 + rb) * 256;
+    if (rb < NKT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[16 * ((lane >> 2) & 3) + (lane & 3) + 64 * i] = g3[i];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rz = 4 * wave + t;
+      if (rz < NKT && (lane & 15) >= 4) {
+        float* z = a.partial + ((long long)blockIdx.x * L::NTILES + 7 * NKT + 49 + rz) * 256 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[64 * r] = 0.0f;
+      }
+    }
+  }
+#endif
 }
 
 // reduced[e] = sum over workgroups of partial[wg][e], fixed order: 64 elements per block, 16 row groups per element (thread
@@ -963,12 +1088,13 @@ struct WgradWs {  // float offsets into the workspace
 
 static WgradWs carve_wgrad(const OnfGeom& g, long long P, int nkt) {
   WgradWs w;
+  const long long hrow = HS;
   w.win = 16 * nkt;
   w.ntiles = 8 * nkt + 49;
   w.grid_cap = onf_train_grid_upper_bound();
   long long o = 0;
-  w.h1 = o; o += P * HS;       // the kernel addresses these four back to back (f4_source): keep the order
-  w.dh1 = o; o += P * HS;
+  w.h1 = o; o += P * hrow;     // the kernel addresses these four back to back (f4_source): keep the order
+  w.dh1 = o; o += P * hrow;
   w.de = o; o += P * w.win;
   w.rec = o; o += P * 12;
   w.loss = o; o += (long long)w.grid_cap * (WAVES > 8 ? WAVES : 8);   // pass 1 writes one row per wave (onf_x32.hip: always 8 per workgroup)

@@ -95,6 +95,9 @@ for k, v in times.items():
     print("%-8s median %.4f ms  min %.4f  (rounds: %s)" % (k, float(np.median(v)), min(v), " ".join("%.3f" % x for x in v)))
 print("variant / product (median): %.4f" % (np.median(times["variant"]) / np.median(times["product"])))
 print("outputs identical:", bool(torch.equal(out["product"], out["variant"])))
+if KERNEL == "k2":
+    for name in ("lam", "cm", "adam_m", "adam_v"):
+        print("  %s identical: %s" % (name, bool(torch.equal(getattr(engs["product"], name), getattr(engs["variant"], name)))))
 if KERNEL == "k1" and not torch.equal(out["product"], out["variant"]):
     d = (out["product"] - out["variant"]).abs().reshape(-1, 4)
     scale = out["product"].abs().reshape(-1, 4).amax(0)
