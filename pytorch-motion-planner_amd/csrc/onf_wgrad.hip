@@ -657,13 +657,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     // x32 order (slots = feature indices): the positional quads are dealt to the first threads, the quads that can hold angle /
     // ones / pad slots to the last ones, so that whole WAVES evaluate positional features only and skip the angle argument and
     // the select (4 of 14 instructions per feature; the evaluation is 40 % of the staging waves' work)
+#ifdef NFOPP_POSITIONAL_WAVES
     constexpr int NPQ = XO ? (NKT >= 13 ? 50 : 25) : 0, NSQ = W4 - NPQ;   // encoding-layer features / 4 (200 or 100 of them)
     const int in_s4 = !XO ? it_in % W4 : (it_in < NPQ * SP ? it_in % NPQ : NPQ + (it_in - NPQ * SP) % NSQ);
     const int in_q0 = !XO ? it_in / W4 : (it_in < NPQ * SP ? it_in / NPQ : (it_in - NPQ * SP) / NSQ);
-#ifdef NFOPP_ABL2_GENERIC_FEATURES   /* development A/B: every wave on the general evaluation */
-    const bool pos_only = false;
 #else
+    const int in_s4 = it_in % W4, in_q0 = it_in / W4;
+#endif
+    // OFF by default (make EXTRA=-DNFOPP_POSITIONAL_WAVES): same-box A/B at P = 2.54 M, twice: 1.738 ms with it, 1.680 ms without
+    // -- the instructions saved are fewer than what the changed slot-to-thread map costs the split stores.
+#ifdef NFOPP_POSITIONAL_WAVES
     const bool pos_only = XO && (wave - WG_WAVES / 2) * 64 + 63 < NPQ * SP;   // wave-uniform
+#else
+    const bool pos_only = false;
 #endif
     f32x4 t_wx, t_wy, t_b, t_fr, t_qh, t_isa;
     {
