@@ -489,6 +489,16 @@ __device__ __forceinline__ void mfma_split_pair(const s16x8 (&a)[3], const s16x8
   c0 = mfma_bf16(a[0], b0[1], c0); c1 = mfma_bf16(a[0], b1[1], c1);
   c0 = mfma_bf16(a[0], b0[0], c0); c1 = mfma_bf16(a[0], b1[0], c1);
 }
+// The same with an A operand that is EXACT in one bf16 level (a 0 / 1 mask): three products, nothing dropped
+__device__ __forceinline__ void mfma_mask_pair(const s16x8& a, const s16x8 (&b0)[3], const s16x8 (&b1)[3], f32x4& c0, f32x4& c1) {
+#ifdef NFOPP_ABL2_NO_MFMA
+  asm volatile("" :: "v"(a), "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]));
+  return;
+#endif
+  c0 = mfma_bf16(a, b0[2], c0); c1 = mfma_bf16(a, b1[2], c1);
+  c0 = mfma_bf16(a, b0[1], c0); c1 = mfma_bf16(a, b1[1], c1);
+  c0 = mfma_bf16(a, b0[0], c0); c1 = mfma_bf16(a, b1[0], c1);
+}
 // XO: the factors are in x32 order (WgradArgs::x32_order, a.x32_order == XO)
 template <int NKT, bool XO>
 __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const WgradArgs a) {
@@ -617,32 +627,31 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       st = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rq * 48 + 16 * rc, 0, 0));
 #endif
     };
-    // XO: dh2 = rho * [a2 > 0] takes only the values rho and 0, so rho is split ONCE per sample, here: the record's unused
-    // words 5..7 carry its three levels, each in both halves of the word, and a dh2 pair is a level word ANDed with a mask
     auto commit_rec = [&](f32x4 st, int parity) __attribute__((always_inline)) {
-      if (XO && rc == 1) {
-        float r = st.x;
-        const unsigned h = __float_as_uint(r) & 0xffff0000u;
-        r -= __uint_as_float(h);
-        const unsigned m = __float_as_uint(r) & 0xffff0000u;
-        r -= __uint_as_float(m);
-        const unsigned l = __float_as_uint(r) & 0xffff0000u;   // exact: the third level's low half-word is zero
-        st.y = __uint_as_float(h | (h >> 16)); st.z = __uint_as_float(m | (m >> 16)); st.w = __uint_as_float(l | (l >> 16));
-      }
       *reinterpret_cast<f32x4*>(lds + L::REC + parity * KS * 12 + rq * 12 + 4 * rc) = st;
     };
-    auto commit_h = [&](int img, const f32x4 (&st)[N_H]) __attribute__((always_inline)) {
+    // rho_rec: x32 order, h1 only -- the rows are scaled by the sample's rho (record word 4) before the split, because G2's other
+    // factor is then the bare mask [a2 > 0], exact in ONE bf16 level: S = sum_p [a2_p > 0] (rho_p h1_p), three partial products
+    // instead of six and one image plane of dh2 instead of three (round 4; the same sum as (rho [a2 > 0]) h1, rounded at a
+    // different place)
+    auto commit_h = [&](int img, const f32x4 (&st)[N_H], const float* rho_rec = nullptr) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < N_H; ++j) {
         int q, c;
         unpack(hqc[j], q, c);
+        f32x4 v = st[j];
+        if (rho_rec) {   // (element by element: a vector-typed multiply becomes v_pk_mul_f32 ... op_sel, which the build check bans)
+          const float rho = rho_rec[q * 12 + 4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * rho;
+        }
 #ifdef NFOPP_ABL2_NO_SPLIT_H   /* development ablation (timing only): h1 / dh1 committed without the split arithmetic */
         const u32x2 raw{__float_as_uint(st[j].x), __float_as_uint(st[j].z)};
         *reinterpret_cast<u32x2*>(lds + img + q * L::R_H + 2 * c) = raw;
         *reinterpret_cast<u32x2*>(lds + img + L::P_H + q * L::R_H + 2 * c) = raw;
         *reinterpret_cast<u32x2*>(lds + img + 2 * L::P_H + q * L::R_H + 2 * c) = u32x2{__float_as_uint(st[j].y), __float_as_uint(st[j].w)};
 #else
-        store_split4(lds, img, L::P_H, q * L::R_H + 2 * c, st[j]);
+        store_split4(lds, img, L::P_H, q * L::R_H + 2 * c, v);
 #endif
       }
     };
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     auto stage_b = [&](auto set_c, long long chunk) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
       const float* rec = lds + L::REC + S * KS * 12;
-      commit_h(L::B_H1, st_h1);
+      commit_h(L::B_H1, st_h1, XO ? rec : nullptr);
       load_h(ws_h1, st_h1, chunk + step);
       WG_TICK(5)
 #pragma unroll
@@ -734,16 +743,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
       for (int j = 0; j < N_H; ++j) {   // dh2 slots 4c .. 4c+3 = rho * W3a * [a2 > 0]: tile c >> 2, lane group c & 3
         int q, c;
         unpack(hqc[j], q, c);
-        if constexpr (XO) {   // (W3a is applied by the gather kernel)
-          const f32x4 lv = *reinterpret_cast<const f32x4*>(rec + q * 12 + 4);   // rho | its levels, doubled
+        if constexpr (XO) {   // the bare mask [a2 > 0] as bf16 1.0 / 0 (rho rides on h1, W3a is applied by the gather kernel)
           const int word = (int)__float_as_uint(rec[q * 12 + 8 + (c & 3)]), sh = 4 * (c >> 2);
           const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(word, sh, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 1, 1);
           const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 3, 1);
           const unsigned k01 = __builtin_amdgcn_perm(m1, m0, 0x07060302), k23 = __builtin_amdgcn_perm(m3, m2, 0x07060302);
-          const int at = q * L::R_H + 2 * c;
-          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + at) = u32x2{__float_as_uint(lv.y) & k01, __float_as_uint(lv.y) & k23};
-          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + L::P_H + at) = u32x2{__float_as_uint(lv.z) & k01, __float_as_uint(lv.z) & k23};
-          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + 2 * L::P_H + at) = u32x2{__float_as_uint(lv.w) & k01, __float_as_uint(lv.w) & k23};
+          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + q * L::R_H + 2 * c) = u32x2{k01 & 0x3f803f80u, k23 & 0x3f803f80u};
           continue;
         }
         const unsigned bits = __float_as_uint(rec[q * 12 + 8 + (c & 3)]) >> (4 * (c >> 2));
@@ -851,26 +856,30 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
 
   // 7 row blocks against one pair of column blocks; the A fragments ping-pong between two register sets (no copies)
   // (image geometry as compile-time constants: row length and level step of the A image and of the B image)
+  // NA = levels of the A operand: 3, or 1 for an A that is exact in one bf16 level (the mask of G2 in x32 order)
   auto mul_pair = [&](const float* a_base, const float* b0_base, const float* b1_base, auto ra_c, auto la_c, auto rb_c, auto lb_c,
-                      f32x4 (&c0)[7], f32x4 (&c1)[7]) __attribute__((always_inline)) {
+                      auto na_c, f32x4 (&c0)[7], f32x4 (&c1)[7]) __attribute__((always_inline)) {
     constexpr int RA = decltype(ra_c)::value, LA = decltype(la_c)::value, RB = decltype(rb_c)::value, LB = decltype(lb_c)::value;
-    s16x8 bf0[3], bf1[3], af[2][3];
+    constexpr int NA = decltype(na_c)::value;
+    s16x8 bf0[3], bf1[3], af[2][NA];
     mfma_guard();   // the fragment registers below were operands of the MFMAs just issued
 #pragma unroll
     for (int lv = 0; lv < 3; ++lv) {
       bf0[lv] = read_frag<RB>(b0_base, lv * LB);
       bf1[lv] = read_frag<RB>(b1_base, lv * LB);
-      af[0][lv] = read_frag<RA>(a_base, lv * LA);
     }
+#pragma unroll
+    for (int lv = 0; lv < NA; ++lv) af[0][lv] = read_frag<RA>(a_base, lv * LA);
     static_for<0, 7>([&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
       if constexpr (r + 1 < 7) {
         if constexpr (r > 0) mfma_guard();   // set (r + 1) & 1 was read by step r - 1's MFMAs, issued just before
 #pragma unroll
-        for (int lv = 0; lv < 3; ++lv) af[(r + 1) & 1][lv] = read_frag<RA>(a_base, lv * LA + 8 * (r + 1));
+        for (int lv = 0; lv < NA; ++lv) af[(r + 1) & 1][lv] = read_frag<RA>(a_base, lv * LA + 8 * (r + 1));
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_split_pair(af[r & 1], bf0, bf1, c0[r], c1[r]);
+      if constexpr (NA == 3) mfma_split_pair(af[r & 1], bf0, bf1, c0[r], c1[r]);
+      else mfma_mask_pair(af[r & 1][0], bf0, bf1, c0[r], c1[r]);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -890,13 +899,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     using ic_pin = std::integral_constant<int, L::P_IN>;
     using ic_rh = std::integral_constant<int, L::R_H>;
     using ic_ph = std::integral_constant<int, L::P_H>;
-    mul_pair(bA_dh1, bA_in, bA_in + 32, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, acc1[0], acc1[1]);
-    mul_pair(bA_dh1, bA_in + 64, bA_in + 96, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, acc1[2], acc1[3]);
+    using ic3 = std::integral_constant<int, 3>;
+    mul_pair(bA_dh1, bA_in, bA_in + 32, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, ic3{}, acc1[0], acc1[1]);
+    mul_pair(bA_dh1, bA_in + 64, bA_in + 96, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, ic3{}, acc1[2], acc1[3]);
     WG_TICK(0)
     phase_barrier();
     WG_TICK(1)
     // phase B: G2 and G3 out of bufB
-    mul_pair(bB_dh2, bB_h1a, bB_h1b, ic_rh{}, ic_ph{}, ic_rf{}, ic_lf{}, acc2[0], acc2[1]);
+    mul_pair(bB_dh2, bB_h1a, bB_h1b, ic_rh{}, ic_ph{}, ic_rf{}, ic_lf{}, std::integral_constant<int, XO ? 1 : 3>{}, acc2[0], acc2[1]);
 #if !defined(NFOPP_ABL2_NO_G3) && !defined(NFOPP_G3_16X16)
     if (g3_mine) {
 #pragma unroll
