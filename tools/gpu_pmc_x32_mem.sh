@@ -10,12 +10,15 @@ run() { name=$1; shift
 }
 run m1 TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE
 run m2 TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
-run m3 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TC_STALL_sum
+# (round 3 asked for these four in ONE pass: rocprofv3 aborted with "Request exceeds the capabilities of the hardware to collect";
+# two counters per pass fit)
+run m3a TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum
+run m3b TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TC_STALL_sum
 run m4 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum
 cd $R
 python3 - <<'PY'
 import csv, glob, collections
-for name in ("m1","m2","m3","m4"):
+for name in ("m1","m2","m3a","m3b","m4"):
     agg = collections.defaultdict(list)
     for f in glob.glob("gpurun_out/pmc_x32_mem/%s/**/*counter_collection.csv" % name, recursive=True):
         for row in csv.DictReader(open(f)):
