@@ -277,7 +277,7 @@ def pmc_traffic(workload, batch, n):
     with tools/gpu_pmc_split.sh on the cfg3 workload in separate --pmc passes); None for other workloads."""
     if (workload, batch, n) != ("cfg3", B_PER_GPU, 256):
         return None, None
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)["bytes_per_launch"]), "profiles/" + name

@@ -246,3 +246,27 @@ def test_device_trig_and_philox_restatements():
     u = gc.philox_uniform_np(100, np.arange(100000), 7)
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 5e-3 and abs(u.var() - 1 / 12) < 2e-3
     assert not np.array_equal(u, gc.philox_uniform_np(101, np.arange(100000), 7))
+
+
+def test_traj_steps_validates_its_arguments_without_a_gpu():
+    """nfopp_traj_steps (ABI 6): the argument checks run before any launch, so they can be exercised here -- and a call for zero
+    steps is a no-op that needs no device."""
+    import ctypes
+    lib = _lib.load()
+    cfg = _lib.OnfConfigC(0.0, 1.0, 1, 1, 10)
+    hp = _lib.TrajHyperC()
+    buf = _lib.TrajBuffersC()
+    buf.batch, buf.n_waypoints, buf.dim = 1, 8, 3
+    buf.u_dev = 4096                       # never dereferenced: n_steps = 0 / the checks fail first
+    sched = _lib.StepScheduleC(0.01, 0.9, 0.9, 0, 0, 0, 1, 0, 10, 1)
+    params = ctypes.c_void_p(4096)
+    assert lib.nfopp_traj_steps(cfg, params, hp, buf, sched, 0, None, None, None) == 0
+    sched.reparam_freq = 0
+    assert lib.nfopp_traj_steps(cfg, params, hp, buf, sched, 0, None, None, None) == -1
+    assert b"reparam_freq" in lib.nfopp_last_error()
+    sched.reparam_freq, sched.t_mode = 10, 0
+    assert lib.nfopp_traj_steps(cfg, params, hp, buf, sched, 3, None, None, None) == -1      # injected draws without a buffer
+    assert b"t_steps_dev" in lib.nfopp_last_error()
+    sched.t_mode = 2
+    assert lib.nfopp_traj_steps(cfg, params, hp, buf, sched, 0, None, None, None) == -1
+    assert lib.nfopp_traj_steps(None, params, hp, buf, sched, 0, None, None, None) == -1
