@@ -744,12 +744,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
         int q, c;
         unpack(hqc[j], q, c);
         if constexpr (XO) {   // the bare mask [a2 > 0] as bf16 1.0 / 0 (rho rides on h1, W3a is applied by the gather kernel)
+#ifdef NFOPP_MASK_BY_STAGING_WAVES   /* A/B: round 4 first had the staging waves write it */
           const int word = (int)__float_as_uint(rec[q * 12 + 8 + (c & 3)]), sh = 4 * (c >> 2);
           const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(word, sh, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 1, 1);
           const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 3, 1);
           const unsigned k01 = __builtin_amdgcn_perm(m1, m0, 0x07060302), k23 = __builtin_amdgcn_perm(m3, m2, 0x07060302);
           *reinterpret_cast<u32x2*>(lds + L::B_DH2 + q * L::R_H + 2 * c) = u32x2{k01 & 0x3f803f80u, k23 & 0x3f803f80u};
-          continue;
+#endif
+          continue;   // (default: the MULTIPLYING waves write the mask plane behind G1, in the time they would wait at the barrier)
         }
         const unsigned bits = __float_as_uint(rec[q * 12 + 8 + (c & 3)]) >> (4 * (c >> 2));
         const float rho = rec[q * 12 + 4];
@@ -891,6 +893,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
   float wg_ticks[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned long long wg_t0 = __builtin_readcyclecounter();
 #endif
+  int par = 0;   // record area of the chunk being multiplied (the staging waves' register-set parity)
   for (long long chunk = c0; chunk < n_chunks; chunk += step) {
     // phase A: G1 out of bufA
     using ic_rf = std::integral_constant<int, R_F>;
@@ -902,6 +905,25 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     using ic3 = std::integral_constant<int, 3>;
     mul_pair(bA_dh1, bA_in, bA_in + 32, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, ic3{}, acc1[0], acc1[1]);
     mul_pair(bA_dh1, bA_in + 64, bA_in + 96, ic_rf{}, ic_lf{}, ic_rin{}, ic_pin{}, ic3{}, acc1[2], acc1[3]);
+#ifndef NFOPP_MASK_BY_STAGING_WAVES
+    if constexpr (XO) {
+      // The mask plane of dh2 for THIS chunk (read by G2 in phase B), from the sign words of record area `par`: the staging waves
+      // bound both phases (8.6 k cycles per chunk against 5.8 k here), these waves would wait ~1.5 k cycles at the barrier below,
+      // and the item needs no registers to speak of (one LDS word in, one 8-byte store out).
+      const float* rec = lds + L::REC + par * KS * 12;
+#pragma unroll
+      for (int j = 0; j < (KS * H4 + WG_THREADS / 2 - 1) / (WG_THREADS / 2); ++j) {
+        const int idx = tid + j * (WG_THREADS / 2), it = idx < KS * H4 ? idx : KS * H4 - 1;   // surplus threads repeat the last item
+        const int q = it / H4, c = it - q * H4;
+        const int word = (int)__float_as_uint(rec[q * 12 + 8 + (c & 3)]), sh = 4 * (c >> 2);
+        const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(word, sh, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 1, 1);
+        const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 3, 1);
+        const unsigned k01 = __builtin_amdgcn_perm(m1, m0, 0x07060302), k23 = __builtin_amdgcn_perm(m3, m2, 0x07060302);
+        *reinterpret_cast<u32x2*>(lds + L::B_DH2 + q * L::R_H + 2 * c) = u32x2{k01 & 0x3f803f80u, k23 & 0x3f803f80u};
+      }
+      par ^= 1;
+    }
+#endif
     WG_TICK(0)
     phase_barrier();
     WG_TICK(1)
