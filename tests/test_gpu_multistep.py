@@ -122,3 +122,23 @@ def test_traj_steps_torch_op_equals_the_ctypes_path():
                        torch.zeros(3, 2, 63, device="cuda"), e.seed, e.rng_offset, e.traj_index_offset, e.onf_out, e.hinv_band,
                        e.half_width, e.interior[0], e.interior[1], e.u, torch_ops.hyper_list(hp.to_c(1)), float(hp.lr),
                        float(hp.betas[0]), float(hp.betas[1]), e.adam_step, b.step_count, b.reparam_freq, 13, None, None, None)
+
+
+def test_step_n_honours_the_active_mask():
+    """Early stop inside `step(n)`: retired trajectories are compacted out of the ONF kernel and skipped by the update and the
+    reparametrisation in every one of the n steps -- their state stays bit for bit, the live ones equal n single steps."""
+    z = load_golden("traj_n100_hard.npz")
+    onf, cfg = gc.make_onf(z["cfg"], z["params"])
+    hp = gc.hyper_from(orc.Hyper.from_npz(z))
+    one, many = _batch(onf, hp, 5, 64), _batch(onf, hp, 5, 64)
+    for p in (one, many):
+        p.step(n=3)
+        p.engine.active = torch.tensor([1, 0, 1, 0, 1], dtype=torch.uint8, device="cuda")
+    frozen = [x.clone() for x in (many.engine.traj, many.engine.lam, many.engine.cm, many.engine.adam_m)]
+    for _ in range(12):
+        one.step()
+    many.step(n=12)
+    _same(_state(one), _state(many))
+    for before, after in zip(frozen, (many.engine.traj, many.engine.lam, many.engine.cm, many.engine.adam_m)):
+        assert torch.equal(before[1], after[1]) and torch.equal(before[3], after[3])
+        assert not torch.equal(before[0], after[0])
