@@ -324,7 +324,16 @@ static_assert(LOOK == 3 || LOOK == 6, "look-ahead of the third-level fragments")
 // One MFMA step for NT point tiles that share the weight fragments: the six partial products in the order of step6, each
 // issued for tile 0 .. NT-1 in turn (independent accumulators alternate on the matrix pipe); WORK(slot) runs behind MFMA
 // number slot - SLOT0 (6 NT slots per step).
-template <int NT, int SLOT0, bool FIRST, class W>
+#ifdef X32_ABL_TILE3_HALF   /* 1: L1's fourth output tile, 2: L1, L2 and L2^T */
+#define X32_HALF_L1(mt) ((mt) == 3)
+#define X32_HALF_L2(mt) ((mt) == 3 && X32_ABL_TILE3_HALF >= 2)
+#else
+#define X32_HALF_L1(mt) false
+#define X32_HALF_L2(mt) false
+#endif
+// HALF (timing-only ablation X32_ABL_TILE3_HALF, results wrong): the step's six products as v_mfma_f32_16x16x32_bf16 -- the same
+// number of matrix instructions and hook slots at half the pipe cycles each: what a 16-row remainder tile could save at best
+template <int NT, int SLOT0, bool FIRST, bool HALF = false, class W>
 __device__ __forceinline__ void stepN(f32x16 (&acc)[NT], const u32x4& ah, const u32x4& am, const u32x4& al,
                                       const u32x4 (&b)[NT][3], W&& work) {
   sfor<0, 6>([&](auto pc) {
@@ -333,7 +342,16 @@ __device__ __forceinline__ void stepN(f32x16 (&acc)[NT], const u32x4& ah, const 
       constexpr int T = decltype(tc)::value;
       const u32x4& a_ = p == 0 ? al : ((p == 2 || p == 3) ? am : ah);
       const u32x4& b_ = b[T][p == 1 ? 2 : ((p == 2 || p == 4) ? 1 : 0)];
-      if constexpr (FIRST && p == 0) {
+      if constexpr (HALF) {
+        f32x4 c4 = {acc[T][0], acc[T][1], acc[T][2], acc[T][3]};
+        if constexpr (FIRST && p == 0) c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c4, 0, 0, 0);
+        acc[T][0] = c4[0]; acc[T][1] = c4[1]; acc[T][2] = c4[2]; acc[T][3] = c4[3];
+        if constexpr (FIRST && p == 0) {
+#pragma unroll
+          for (int r = 4; r < 16; ++r) acc[T][r] = 0.0f;
+        }
+      } else if constexpr (FIRST && p == 0) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         acc[T] = mfma32(a_, b_, zero);
       } else {
@@ -658,7 +676,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           }
           fl[(4 * PAR + mt + LOOK) & (RL - 1)] = lo_frag(C::S_L1 + 4 * kb + mt + LOOK);
           __builtin_amdgcn_sched_barrier(0);
-          stepN<NT, 6 * NT * mt, FIRST>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[(4 * PAR + mt) & (RL - 1)], bc, [&](auto slot) {
+          stepN<NT, 6 * NT * mt, FIRST, X32_HALF_L1(mt)>(acc1[mt], fh[mt & 1], fm[mt & 1], fl[(4 * PAR + mt) & (RL - 1)], bc, [&](auto slot) {
             if constexpr (HOOK == 1) sfor<0, 5>([&](auto i) { l1_item(ic<5 * decltype(slot)::value + decltype(i)::value>{}, bn); });
             if constexpr (HOOK == 2) sfor<0, 6>([&](auto i) { l1_item_any(ic<6 * decltype(slot)::value + decltype(i)::value>{}, bn); });
           });
@@ -731,7 +749,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           }
           fl[(C::S_L2 + 4 * kb + mt + LOOK) & (RL - 1)] = lo_frag(C::S_L2 + 4 * kb + mt + LOOK);
           __builtin_amdgcn_sched_barrier(0);
-          stepN<NT, 6 * NT * mt, kb == 0>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[(C::S_L2 + 4 * kb + mt) & (RL - 1)], bb[kb & 1], [&](auto slot) {
+          stepN<NT, 6 * NT * mt, kb == 0, X32_HALF_L2(mt)>(acc2[mt], fh[mt & 1], fm[mt & 1], fl[(C::S_L2 + 4 * kb + mt) & (RL - 1)], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, 3>([&](auto i) { h1_item(ic<kb + 1>{}, ic<3 * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
@@ -828,7 +846,7 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
           else if constexpr (kb + 1 < HK) fetch(kb + 1, 0, kb + 1 == 6, 0);
           fl[(C::S_L2T + 4 * kb + mt + LOOK) & (RL - 1)] = lo_frag(C::S_L2T + 4 * kb + mt + LOOK);
           __builtin_amdgcn_sched_barrier(0);
-          stepN<NT, 6 * NT * mt, kb == 0>(accd[mt], fh[mt & 1], fm[mt & 1], fl[(C::S_L2T + 4 * kb + mt) & (RL - 1)], bb[kb & 1], [&](auto slot) {
+          stepN<NT, 6 * NT * mt, kb == 0, X32_HALF_L2(mt)>(accd[mt], fh[mt & 1], fm[mt & 1], fl[(C::S_L2T + 4 * kb + mt) & (RL - 1)], bb[kb & 1], [&](auto slot) {
             if constexpr (kb + 1 < HK)
               sfor<0, DH2_PS>([&](auto i) { dh2_item(ic<kb + 1>{}, ic<DH2_PS * decltype(slot)::value + decltype(i)::value>{}, bb[(kb + 1) & 1]); });
           });
