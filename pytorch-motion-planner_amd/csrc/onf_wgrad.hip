@@ -482,6 +482,11 @@ __device__ __forceinline__ void mfma_split_pair(const s16x8 (&a)[3], const s16x8
   asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]));
   return;
 #endif
+#ifdef NFOPP_ABL2_HALF_MFMA   /* development ablation (timing only): half the matrix instructions (what 32x32x16 tiles would issue) */
+  c0 = mfma_bf16(a[2], b0[0], c0); c0 = mfma_bf16(a[0], b0[2], c0); c0 = mfma_bf16(a[1], b0[1], c0);
+  c1 = mfma_bf16(a[1], b1[0], c1); c1 = mfma_bf16(a[0], b1[1], c1); c1 = mfma_bf16(a[0], b1[0], c1);
+  return;
+#endif
   c0 = mfma_bf16(a[2], b0[0], c0); c1 = mfma_bf16(a[2], b1[0], c1);
   c0 = mfma_bf16(a[0], b0[2], c0); c1 = mfma_bf16(a[0], b1[2], c1);
   c0 = mfma_bf16(a[1], b0[1], c0); c1 = mfma_bf16(a[1], b1[1], c1);
@@ -813,6 +818,194 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_split_kernel(const Wg
     return;
   }
 
+#ifndef NFOPP_WGRAD_16X16
+  if constexpr (XO) {
+    // ================== consumers, x32 order (round 4): waves 0..3 multiply on v_mfma_f32_32x32x16_bf16 ==================
+    // The 16x16x32 form below issues 210 bf16 matrix instructions per wave and chunk, each holding the SIMD's vector issue port for 8
+    // of its 16 cycles -- the port this wave shares with its staging partner, whose instruction total bounds the kernel (timing
+    // ablation with half the matrix instructions: -8 %).  32x32x16 tiles need half as many issues for the same products.
+    //   G1 = dh1^T in: 4 x 7 tiles of 32 x 32 (rows 112..127 are whatever lies behind the 112 slots of an image row: garbage that
+    //        only reaches result rows that are never stored); wave w owns row tile w, all 7 column tiles, K = 2 steps of 16 samples.
+    //   G2 = mask^T (rho h1): 4 x 4 tiles, wave w owns row tile w; the mask is exact in one level: 3 products per step.
+    // Fragments by ds_read_b64_tr_b16 from the SAME sample-major images: lane (i = lane & 31, g = lane >> 5) holds slot 32 T + i for
+    // the samples 16 ks + 8 g + {0..7}: two reads of four sample rows; a 16-lane group covers 16 slots (8 dwords) of 4 rows.
+    // The first read takes the EVEN rows of the eight, the second the odd ones (A and B alike, so k pairs up): with rows of
+    // 8 * odd dwords the eight (row, column half) pieces of a 32-lane half -- at 2 q R + 8 h dwords, q = 0..3, h = 0, 1 -- start at
+    // eight different multiples of 8 banks (2 R / 8 = 2 or 6 mod 8): conflict-free; four CONSECUTIVE rows overlap pairwise.
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int qq = (lane & 15) >> 2, pp = lane & 3;
+    const int rowl = 8 * (lane >> 5) + 2 * qq, coll = 8 * ((lane >> 4) & 1) + 2 * pp;
+    static_assert((L::R_H / 8) % 2 == 1 && (L::R_IN / 8) % 2 == 1 && L::R_H % 8 == 0 && L::R_IN % 8 == 0, "bank pattern of the 32-wide transposing reads");
+    const float* const fA_dh1 = lds + L::A_DH1 + rowl * L::R_H + coll + 16 * wave;
+    const float* const fA_in = lds + L::A_IN + rowl * L::R_IN + coll;
+    const float* const fB_msk = lds + L::B_DH2 + rowl * L::R_H + coll + 16 * wave;
+    const float* const fB_h1 = lds + L::B_H1 + rowl * L::R_H + coll;
+    auto frag32 = [](const float* base, int dword_off, auto r_c) __attribute__((always_inline)) {
+      constexpr int R = decltype(r_c)::value;
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + dword_off));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + dword_off + R));
+      return s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    };
+    auto mm = [](const s16x8& x, const s16x8& y, f32x16 c) __attribute__((always_inline)) {
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+    };
+    using ic_rh = std::integral_constant<int, L::R_H>;
+    using ic_rin = std::integral_constant<int, L::R_IN>;
+    constexpr int NCT = (WIN + 31) / 32;   // 32-column tiles of G1 (input slots)
+    f32x16 acc1[NCT], acc2[4];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[t][r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
+    f32x4 acc3e = f32x4{0.f, 0.f, 0.f, 0.f}, acc3o = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* const g3_a = lds + L::B_DE + 64 * wave + lane;
+    const float* const g3_b = lds + L::B_DE + WIN + (lane & 3);
+    const bool g3_mine = 64 * wave < WIN;
+    if (c0 < n_chunks) {
+      phase_barrier();
+      phase_barrier();
+    }
+#ifdef NFOPP_WG_PROFILE
+    float wg_ticks[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long wg_t0 = __builtin_readcyclecounter();
+#endif
+    int par = 0;   // record area of the chunk being multiplied (the staging waves' register-set parity)
+    for (long long chunk = c0; chunk < n_chunks; chunk += step) {
+      // ---- phase A: G1 out of bufA.  Per k step of 16 samples: the A fragments once, the B fragments one column tile ahead
+      {
+        s16x8 af[3], bf[2][3];
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) bf[0][lv] = frag32(fA_in, lv * L::P_IN, ic_rin{});
+        static_for<0, 2 * NCT>([&](auto sc) __attribute__((always_inline)) {
+          constexpr int st = decltype(sc)::value, ks = st / NCT, ct = st % NCT;
+          if constexpr (ct == 0) {
+#pragma unroll
+            for (int lv = 0; lv < 3; ++lv) af[lv] = frag32(fA_dh1, lv * L::P_H + 16 * ks * L::R_H, ic_rh{});
+          }
+          if constexpr (st + 1 < 2 * NCT) {
+            constexpr int ks1 = (st + 1) / NCT, ct1 = (st + 1) % NCT;
+#pragma unroll
+            for (int lv = 0; lv < 3; ++lv) bf[(st + 1) & 1][lv] = frag32(fA_in, lv * L::P_IN + 16 * ct1 + 16 * ks1 * L::R_IN, ic_rin{});
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const s16x8 (&b)[3] = bf[st & 1];
+#ifndef NFOPP_ABL2_NO_MFMA
+          acc1[ct] = mm(af[2], b[0], acc1[ct]);
+          acc1[ct] = mm(af[0], b[2], acc1[ct]);
+          acc1[ct] = mm(af[1], b[1], acc1[ct]);
+          acc1[ct] = mm(af[1], b[0], acc1[ct]);
+          acc1[ct] = mm(af[0], b[1], acc1[ct]);
+          acc1[ct] = mm(af[0], b[0], acc1[ct]);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      {   // the mask plane of dh2 for THIS chunk (see the 16x16x32 form below)
+        const float* rec = lds + L::REC + par * KS * 12;
+#pragma unroll
+        for (int j = 0; j < (KS * H4 + WG_THREADS / 2 - 1) / (WG_THREADS / 2); ++j) {
+          const int idx = tid + j * (WG_THREADS / 2), it = idx < KS * H4 ? idx : KS * H4 - 1;
+          const int q = it / H4, c = it - q * H4;
+          const int word = (int)__float_as_uint(rec[q * 12 + 8 + (c & 3)]), sh = 4 * (c >> 2);
+          const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(word, sh, 1), m1 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 1, 1);
+          const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe(word, sh + 3, 1);
+          const unsigned k01 = __builtin_amdgcn_perm(m1, m0, 0x07060302), k23 = __builtin_amdgcn_perm(m3, m2, 0x07060302);
+          *reinterpret_cast<u32x2*>(lds + L::B_DH2 + q * L::R_H + 2 * c) = u32x2{k01 & 0x3f803f80u, k23 & 0x3f803f80u};
+        }
+        par ^= 1;
+      }
+      WG_TICK(0)
+      phase_barrier();
+      WG_TICK(1)
+      // ---- phase B: G2 and G3 out of bufB
+      {
+        s16x8 am[2], bf[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) am[ks] = frag32(fB_msk, 16 * ks * L::R_H, ic_rh{});
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) bf[0][lv] = frag32(fB_h1, lv * L::P_H, ic_rh{});
+        static_for<0, 8>([&](auto sc) __attribute__((always_inline)) {
+          constexpr int st = decltype(sc)::value, ct = st >> 1, ks = st & 1;
+          if constexpr (st + 1 < 8) {
+            constexpr int ct1 = (st + 1) >> 1, ks1 = (st + 1) & 1;
+#pragma unroll
+            for (int lv = 0; lv < 3; ++lv) bf[(st + 1) & 1][lv] = frag32(fB_h1, lv * L::P_H + 16 * ct1 + 16 * ks1 * L::R_H, ic_rh{});
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const s16x8 (&b)[3] = bf[st & 1];
+          // G3's operands of four samples: read here, multiplied behind this step's matrix instructions (the reads' latency
+          // hides behind them; G3 after G2 in one block left this phase bound by these waves)
+          float ga[4], gb[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ga[j] = g3_a[(4 * st + j) * L::RS_DE]; gb[j] = g3_b[(4 * st + j) * L::RS_DE]; }
+#ifndef NFOPP_ABL2_NO_MFMA
+          acc2[ct] = mm(am[ks], b[2], acc2[ct]);
+          acc2[ct] = mm(am[ks], b[1], acc2[ct]);
+          acc2[ct] = mm(am[ks], b[0], acc2[ct]);
+#endif
+          if (g3_mine) {
+            acc3e = __builtin_amdgcn_mfma_f32_4x4x1f32(ga[0], gb[0], acc3e, 0, 0, 0);
+            acc3o = __builtin_amdgcn_mfma_f32_4x4x1f32(ga[1], gb[1], acc3o, 0, 0, 0);
+            acc3e = __builtin_amdgcn_mfma_f32_4x4x1f32(ga[2], gb[2], acc3e, 0, 0, 0);
+            acc3o = __builtin_amdgcn_mfma_f32_4x4x1f32(ga[3], gb[3], acc3o, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      WG_TICK(2)
+      phase_barrier();
+      WG_TICK(3)
+    }
+#ifdef NFOPP_WG_PROFILE
+    if (blockIdx.x == 0 && tid == 0)
+      printf("consumer wave 0 (32x32x16): G1 %.0f | barrier %.0f | G2+G3 %.0f | barrier %.0f ticks\n", wg_ticks[0], wg_ticks[1], wg_ticks[2],
+             wg_ticks[3]);
+#endif
+    // ---- per-workgroup partial tiles, in the 16 x 16 tile order the reduce / gather kernels read: result (row, col) -> tile
+    // (row / 16, col / 16), element 64 (row & 3) + 16 ((row & 15) >> 2) + (col & 15).  A lane of a 32 x 32 accumulator holds column
+    // lane & 31 and the rows 8 (r >> 2) + 4 (lane >> 5) + (r & 3), r = 0..15.
+    float* const part = a.partial + (long long)blockIdx.x * L::NTILES * 256;
+    const int cj = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + 8 * (r >> 2) + 4 * g + (r & 3), col = 32 * t + cj;
+        if (row < HS && col < WIN) part[((row >> 4) * NKT + (col >> 4)) * 256 + 64 * (row & 3) + 16 * ((row & 15) >> 2) + (col & 15)] = acc1[t][r];
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + 8 * (r >> 2) + 4 * g + (r & 3), col = 32 * t + cj;
+        if (row < HS && col < HS) part[(7 * NKT + (row >> 4) * 7 + (col >> 4)) * 256 + 64 * (row & 3) + 16 * ((row & 15) >> 2) + (col & 15)] = acc2[t][r];
+      }
+    {
+      const f32x4 g3 = acc3e + acc3o;
+      const int rb = 4 * wave + (lane >> 4);
+      float* o = part + (7 * NKT + 49 + rb) * 256;
+      if (rb < NKT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[16 * ((lane >> 2) & 3) + (lane & 3) + 64 * i] = g3[i];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rz = 4 * wave + t;
+        if (rz < NKT && (lane & 15) >= 4) {
+          float* z = part + (7 * NKT + 49 + rz) * 256 + lane;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[64 * r] = 0.0f;
+        }
+      }
+    }
+    return;
+  }
+#endif
   // ================================= consumers: waves 0..3 multiply =======================================================
   // G1 (7 x NKT tiles, dh1^T in): wave w owns the column blocks w, w + 4, w + 8, w + 12, all 7 row blocks each (a column block
   //   past NKT is multiplied on whatever the image holds there and never stored: 28 tiles for every wave).
