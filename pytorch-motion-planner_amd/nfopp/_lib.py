@@ -151,13 +151,25 @@ def require_current_device(tensor_index, current_index):
                          % (tensor_index, current_index))
 
 
+# torch.cuda.current_device() / current_stream() cost 2-9 us per call in Python; a planner step makes ~30 of them, which at
+# B = 1 was a quarter of the step's wall time (tools/b1_breakdown.py).  The raw accessors below are what they wrap.
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _current_device():
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
+
+
 def ptr(t, dtype=torch.float32):
     """Device pointer of a contiguous CUDA(HIP) tensor on the current device, or NULL for None."""
     if t is None:
         return None
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise NfoppError("expected a contiguous %s HIP tensor, got %s" % (dtype, _describe(t)))
-    require_current_device(t.device.index, torch.cuda.current_device())
+    dev = _current_device()
+    if t.device.index != dev:
+        require_current_device(t.device.index, dev)
     return t.data_ptr() or None   # empty tensors have no storage: pass NULL (the C side accepts it for size 0)
 
 
@@ -168,4 +180,7 @@ def _describe(t):
 
 
 def stream_ptr():
+    """hipStream_t of the CURRENT stream of the current device, as an integer."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream

@@ -86,6 +86,11 @@ class TrajectoryHyper(object):
         b1, b2 = self.betas
         bc1 = 1 - b1 ** adam_step
         bc2 = 1 - b2 ** adam_step
+        c = getattr(self, "_c_block", None)
+        if c is not None:                    # the step-invariant fields were filled when the block was made (the object is
+            c.adam_step_size = self.lr / bc1   # treated as immutable: the planners build a new one when a scalar changes)
+            c.adam_bc2_sqrt = math.sqrt(bc2)
+            return c
         c = _lib.TrajHyperC()
         c.collision_weight = self.collision_weight
         c.angle_weight = self.angle_weight
@@ -103,6 +108,7 @@ class TrajectoryHyper(object):
         c.adam_eps = self.eps
         c.adam_step_size = self.lr / bc1
         c.adam_bc2_sqrt = math.sqrt(bc2)
+        self._c_block = c
         return c
 
 

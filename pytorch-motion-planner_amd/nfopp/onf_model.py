@@ -118,7 +118,11 @@ class ONF(nn.Module):
         write to the parameters by ANY means (in-place ops, `.data`, `dist.broadcast`, a foreign kernel) shows in the very
         next evaluation.  Image reuse is OPT-IN: see `freeze()`."""
         self._vouch()
-        return _lib.OnfConfigC(self._mean, self._sigma, int(self._use_cos), int(self._bias), self._angle_dim)
+        c = self.__dict__.get("_cfg_block")
+        if c is None:
+            c = _lib.OnfConfigC(self._mean, self._sigma, int(self._use_cos), int(self._bias), self._angle_dim)
+            object.__setattr__(self, "_cfg_block", c)
+        return c
 
     # ---- weight-image reuse (ABI 5 content versions): opt-in ------------------------------------------------------
     def freeze(self):

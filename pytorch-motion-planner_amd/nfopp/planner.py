@@ -113,8 +113,13 @@ class NERFOptPlanner(ContinuousPlanner):
                                bounds=self._random_sample_border)
 
     def _sync_hyper(self):
-        """Attributes may be edited between steps (drivers do); rebuild the kernel scalars each step."""
-        self._engine.hyper = self._make_hyper()
+        """Attributes may be edited between steps (drivers do): the kernel scalars follow them, rebuilt only when one changed."""
+        h = self._make_hyper()
+        key = (h.collision_weight, h.angle_weight, h.constraint_deltas_weight, h.multipliers_lr, h.collision_multipliers_lr,
+               h.boundary_weight, h.collision_beta, h.direction_delta_weight, h.lr, h.betas, h.eps, h.bounds)
+        if key != getattr(self, "_hyper_key", None):
+            self._hyper_key = key
+            self._engine.hyper = h
 
     @property
     def _start_point(self):
@@ -173,9 +178,11 @@ class NERFOptPlanner(ContinuousPlanner):
         """One BCE/Adam step of the field on host-provided samples: gradient kernel + flat Adam kernel."""
         lib = _lib.load()
         model = self._collision_model
-        samples = torch.tensor(np.ascontiguousarray(positions, dtype=np.float32), device=self._device)
-        labels = torch.tensor(np.asarray(truth).astype(np.float32), device=self._device)
-        p = samples.shape[0]
+        # one upload for poses and labels (two pageable copies cost 2 x 25 us at B = 1): [P * D | P] floats, two contiguous views
+        pos32 = np.ascontiguousarray(positions, dtype=np.float32)
+        p, d = pos32.shape
+        packed = torch.from_numpy(np.concatenate([pos32.reshape(-1), np.asarray(truth).astype(np.float32).reshape(-1)])).to(self._device)
+        samples, labels = packed[:p * d].view(p, d), packed[p * d:]
         cfg = model.config_c()
         need = lib.nfopp_onf_train_workspace_bytes(cfg, p)
         if self._onf_ws is None or self._onf_ws.numel() * 4 < need:
