@@ -351,22 +351,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void onf_wgrad_kernel(const WgradArg
 
 // ---- pass 2 on the bf16 matrix pipe: three-level exact operand split, six partial products per fp32 multiply ---------
 // (the split matrix path, csrc/onf_split.hip's arithmetic: x = hi + mid + lo, products hh, hm, mh, hl, lh, mm -- every
-// dropped term is below 2^-24 of the product).  G1 and G2 carry 97 % of the flops and run as v_mfma_f32_16x16x32_bf16 with
-// K = 32 samples; G3 (de^T u, 4 useful columns) stays on the fp32 MFMA.
+// dropped term is below 2^-24 of the product).  G1 = dh1^T in and G2 = dh2^T h1 carry 97 % of the flops, K = 32 samples per chunk.
+// Factors in x32 order (pass 1 = csrc/onf_x32_impl.h, the default; round 4): v_mfma_f32_32x32x16_bf16, and G2 as
+// mask^T (rho h1) -- the bare ReLU mask is exact in ONE level, so three products, nothing dropped; G3 = de^T u (4 useful
+// columns) on v_mfma_f32_4x4x1_16b_f32.  Factors in the 16x16 kernels' slot order (matrix path 2): v_mfma_f32_16x16x32_bf16
+// throughout, G3 likewise on the 4x4x1 form.
 //
 // LDS images.  Operands are stored SAMPLE-major as bf16, [32 samples][slots], one image per level, and read with the
-// transposing ds_read_b64_tr_b16: lane (i = l & 15, g = l >> 4) gets slot i of four sample rows per read, two reads make
-// the eight k values of its fragment.  Sample order inside a fragment: group g takes rows 16 (g >> 1) + 4 (g & 1) + {0..3}
-// and + 8 -- the same for A and B, so k pairs up -- which puts the 8 rows a 32-lane half reads at once next to each
-// other; with a row length of 8 * odd dwords they cover the 64 banks exactly once (conflict-free).  Staging threads split
-// each float4 once (11 vector instructions per pair) and store 8 bytes per level.
+// transposing ds_read_b64_tr_b16 (a 16-lane group covers 16 slots of 4 sample rows: lane i gets slot i of the four).
+//   16x16x32: lane (i = l & 15, g = l >> 4): group g takes rows 16 (g >> 1) + 4 (g & 1) + {0..3} and + 8 -- the same for A
+//             and B, so k pairs up -- which puts the 8 rows a 32-lane half reads at once next to each other;
+//   32x32x16: lane (i = l & 31, g = l >> 5): the even rows of the half's eight samples in the first read, the odd ones in the second;
+// with a row length of 8 * odd dwords both cover the 64 banks exactly once per 32-lane half (conflict-free).  Staging threads
+// split each float4 once (11 vector instructions per pair) and store 8 bytes per level.
 //
 // Two phases per chunk, one barrier after each; each buffer is filled during the phase that multiplies out of the other:
-//   phase A(k): multiply G1(k) from bufA | stage into bufB: h1(k), dh2(k) (rebuilt from the record), de(k), u(k);
-//               record(k+1) -> record area
-//   phase B(k): multiply G2(k), G3(k) from bufB | stage into bufA: dh1(k+1), in(k+1) (re-evaluated from u(k+1))
-// Every HBM load is issued right after the registers it lands in were committed, two phases (about one chunk time) before
-// its use.  Waves 0..3 multiply, waves 4..7 stage (w and w + 4 share a SIMD: see the kernel).
+//   phase A(k): multiply G1(k) from bufA, then (x32 order) write the mask plane of dh2(k)
+//               | stage into bufB: h1(k) (x32 order: scaled by rho), de(k), u(k), (slot order: dh2(k) from the record);
+//                 evaluate the input features of chunk k+1 into registers (record(k+1) was committed in phase B(k-1))
+//   phase B(k): multiply G2(k), G3(k) from bufB | stage into bufA: dh1(k+1), the split features of chunk k+1; commit record(k+2)
+// One register set per staged array: a chunk's rows are committed at the start of their phase and the same registers re-loaded
+// with the next chunk's rows right behind (a chunk time ahead of use).  Waves 0..3 multiply, waves 4..7 stage (w and w + 4
+// share a SIMD: see the kernel); the staging waves' instruction total bounds the kernel.
 constexpr int KS = 32;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
