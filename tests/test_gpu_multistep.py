@@ -142,3 +142,34 @@ def test_step_n_honours_the_active_mask():
     for before, after in zip(frozen, (many.engine.traj, many.engine.lam, many.engine.cm, many.engine.adam_m)):
         assert torch.equal(before[1], after[1]) and torch.equal(before[3], after[3])
         assert not torch.equal(before[0], after[0])
+
+
+def test_step_n_at_the_benchmark_size_equals_single_steps():
+    """BASELINE configs[2] shape (4096 x 256, the 512-thread workgroup shape of the fused kernel): 12 steps from one call equal
+    12 single steps bit for bit, reparametrisations included."""
+    z = load_golden("traj_benchmr_n256.npz")
+    onf, cfg = gc.make_onf(z["cfg"], z["params"])
+    hp = gc.hyper_from(orc.Hyper.from_npz(z))
+    B, N = 4096, 256
+    rng = np.random.default_rng(3)
+    lo, hi = hp.bounds[0] + 2, hp.bounds[1] - 2
+    starts = np.concatenate([rng.uniform(lo, hi, (B, 2)), rng.uniform(-3, 3, (B, 1))], 1).astype(F32)
+    goals = np.concatenate([rng.uniform(lo, hi, (B, 2)), rng.uniform(-3, 3, (B, 1))], 1).astype(F32)
+    res = []
+    for chunked in (False, True):
+        p = nfopp.BatchPlanner(onf, B, N, hp, device="cuda", seed=100)
+        p.init(starts, goals, hp.bounds)
+        if chunked:
+            p.step(n=12)
+        else:
+            for _ in range(12):
+                p.engine.collision_eval()
+                p.engine.update(False)
+                if p.step_count % p.reparam_freq == 0:
+                    p.engine.reparametrize()
+                p.step_count += 1
+        torch.cuda.synchronize()
+        res.append([x.clone() for x in (p.engine.traj, p.engine.lam, p.engine.cm, p.engine.adam_m, p.engine.adam_v)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][0]).all()
