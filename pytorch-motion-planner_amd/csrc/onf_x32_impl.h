@@ -492,6 +492,13 @@ __global__ __launch_bounds__(XT, XT / 256) void onf_x32_kernel(const OnfKernelAr
 #endif
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)}, r, voff, 0, 0);
   };
+#ifdef X32_STAGGER   /* development A/B (MI355X_MICROARCH.md, two waves per SIMD, item 9): the second-dispatched half of the workgroup
+                        starts X32_STAGGER x 8 k cycles late, so that SIMD partners are out of phase at the GEMM boundaries */
+  if (XT == 512 && wave >= 4) {
+#pragma unroll 1
+    for (int q = 0; q < X32_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     float ux[NT], uy[NT], th[NT];
     long long pidx[NT];
