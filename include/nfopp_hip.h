@@ -252,11 +252,13 @@ int nfopp_path_select_best(const float* labels_dev, const float* length_dev, con
 /* Matrix path of the fused ONF kernels (nfopp_onf_eval_points / _logits / nfopp_traj_collision_eval):
  *   1 (default) = bf16x3 split-precision MFMA: every fp32 operand is split EXACTLY into three bf16 levels and the six
  *       partial products above 2^-24 are accumulated in fp32 on the bf16 matrix pipe -- fp32-faithful (closer to float64
- *       than a sequential fp32 dot product).  Launches that give every CU a full 256-sample chunk run on 32x32x16 tiles
- *       (csrc/onf_x32.hip), smaller ones and the training pass on 16x16x32 tiles (csrc/onf_split.hip).
+ *       than a sequential fp32 dot product).  Every launch of every ONF shape (F = 100 / 120 / 200 / 220) runs on 32x32x16 tiles
+ *       (csrc/onf_x32_impl.h), in two workgroup shapes that are bit-identical per sample: results do not depend on the batch
+ *       size or on how a batch is sharded; the training pass of the ONF fit too.
  *   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/onf_fused.hip).
- *   2 = bf16x3 split, the 16x16x32 kernel at every size;  3 = bf16x3 split, the 32x32x16 kernel at every size.
- *   The environment variable NFOPP_MATRIX_PATH=fp32|0|1|2|3 selects the path at load time.  Process-wide.
+ *   2 = bf16x3 split on the round-2 kernels (16x16x32 tiles, csrc/onf_split.hip) at every size: an independent implementation
+ *       of path 1's arithmetic, kept as a cross-check.
+ *   The environment variable NFOPP_MATRIX_PATH=fp32|0|1|2 selects the path at load time.  Process-wide.
  *   The split paths keep ONE scratch image per (device, stream) (pre-split weights, rebuilt from params_dev by a small
  *   kernel in front of every evaluation on the caller's stream), at most 16 per device: a 17th stream reuses the least
  *   recently used slot after a device synchronisation. */
