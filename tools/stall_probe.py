@@ -41,3 +41,10 @@ for B in (1, 4096):
     go = np.concatenate([rng.uniform(2.2, 2.8, (B, 2)), rng.uniform(-3, 3, (B, 1))], 1).astype(np.float32)
     bp.init(st, go, bounds)
     run("BatchPlanner B=%d step(n=10) per block" % B, lambda: bp.step(n=10))
+# the same B = 1 loop with Python's cyclic garbage collector out of the way: is the one slow block a full (generation-2) collection?
+import gc
+bp = nfopp.BatchPlanner(onf, 1, 256, hyper, device="cuda", seed=1)
+bp.init(st[:1], go[:1], bounds)
+gc.collect(); gc.freeze(); gc.disable()
+run("BatchPlanner B=1 step(n=10) per block, gc frozen + disabled", lambda: bp.step(n=10))
+gc.enable()
